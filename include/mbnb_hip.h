@@ -1,0 +1,154 @@
+/*
+ * mbnb_hip.h — C ABI of the MI355X (gfx950) quantized-linear backend.
+ *
+ * This is the drop-in boundary for the reference's native extension
+ * `mps_bitsandbytes._C` (pybind11 module, mps_bitsandbytes/csrc/mps_bitsandbytes.mm:2726-2800)
+ * on the quantized-linear hot path.  Each entry point names the reference
+ * binding / function it replaces.  Differences from the reference boundary,
+ * by design:
+ *
+ *   - plain C types only: device pointers, int64 sizes, int enums, an opaque
+ *     hipStream_t passed as void*; no torch / ATen types;
+ *   - the CALLER allocates everything (outputs and workspaces); the library
+ *     never allocates, frees or retains device memory;
+ *   - every call is asynchronous on `stream` (no device synchronisation);
+ *     the library is re-entrant and holds no mutable global state;
+ *   - errors are returned as an int status (0 ok, <0 argument error,
+ *     >0 hipError_t); no exception crosses the ABI.  mbnb_last_error()
+ *     returns a thread-local description of the last failure.
+ *
+ * All tensors are dense, row-major, contiguous.  All pointers are DEVICE
+ * pointers on the current HIP device (the caller selects the device).
+ */
+#ifndef MBNB_HIP_H
+#define MBNB_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MBNB_ABI_VERSION 1
+
+/* element dtypes */
+enum { MBNB_F16 = 0, MBNB_BF16 = 1, MBNB_F32 = 2 };
+/* 4-bit code tables: functional.py:21-32 (Metal copies mm:71-85) */
+enum { MBNB_NF4 = 0, MBNB_FP4 = 1 };
+
+/* status codes (<0: argument errors detected on the host before any launch) */
+enum {
+    MBNB_OK = 0,
+    MBNB_ERR_ARG = -1,        /* null pointer / negative size / bad enum */
+    MBNB_ERR_SHAPE = -2,      /* sizes inconsistent with each other */
+    MBNB_ERR_UNSUPPORTED = -3 /* valid in the reference but not implemented here */
+};
+
+int mbnb_abi_version(void);
+/* thread-local, never NULL; valid until the next failing call on this thread */
+const char *mbnb_last_error(void);
+/* name of the kernel family the last mbnb_matmul_4bit / mbnb_linear_int8 call on this thread
+ * dispatched to ("gemv", "mfma128", "generic", ...) — for tests and the bench driver */
+const char *mbnb_last_kernel(void);
+
+/* ---------------------------------------------------------------------------
+ * Absmax descriptor used by the 4-bit consumers.  Either plain f32 absmax
+ * (absmax_i8 == NULL), or the reference's "double quantised" form
+ * (QuantState.state2, functional.py:288-292): int8 codes + one f32 absmax2 per
+ * `blocksize2` (256) codes, decoded in-kernel exactly as dequantize_blockwise
+ * does (functional.py:592-594): absmax[i] = (float)q[i] * (absmax2[i / blocksize2] / 127.0f).
+ * ------------------------------------------------------------------------- */
+typedef struct mbnb_absmax {
+    const float *absmax_f32;  /* [nblocks] or NULL */
+    const int8_t *absmax_i8;  /* [nblocks] or NULL */
+    const float *absmax2;     /* [ceil(nblocks / blocksize2)], required with absmax_i8 */
+    int32_t blocksize2;       /* 256 in the reference */
+} mbnb_absmax;
+
+/* ---------------------------------------------------------------------------
+ * quantize_4bit — replaces functional.quantize_4bit (functional.py:163-303; the
+ * reference's native `_C.quantize_nf4/_fp4`, mm:1892-1925 / :2738, is a dead binding).
+ *   A          [rows, cols] of `dtype`; a non-2-D tensor is passed as rows = 1
+ *   cols_padded = ceil(cols / blocksize) * blocksize (+ blocksize if odd)  (functional.py:219-221)
+ *   absmax_in  optional caller-supplied absmax [rows * cols_padded / blocksize] (the `absmax=` kwarg)
+ *   packed     out, u8 [rows * cols_padded / 2]; byte j = idx[2j] | idx[2j+1] << 4
+ *   absmax_out out, f32 [rows * cols_padded / blocksize]
+ * blocksize: power of two in [1, 65536].  Bit-exact vs the reference CPU path.
+ * ------------------------------------------------------------------------- */
+int mbnb_quantize_4bit(const void *A, int dtype, int64_t rows, int64_t cols, int64_t cols_padded,
+                       int blocksize, int quant_type, const float *absmax_in, uint8_t *packed,
+                       float *absmax_out, void *stream);
+
+/* dequantize_4bit — replaces functional.dequantize_4bit (functional.py:306-416; dead native
+ * binding `_C.dequantize_nf4/_fp4`, mm:1927-1954 / :2739).  out [rows, cols] of out_dtype. */
+int mbnb_dequantize_4bit(const uint8_t *packed, const mbnb_absmax *absmax, int64_t rows,
+                         int64_t cols, int64_t cols_padded, int blocksize, int quant_type,
+                         int out_dtype, void *out, void *stream);
+
+/* quantize_blockwise — functional.py:469-539 (int8, flat blocks; used for the absmax
+ * double-quant at :291 with blocksize 256).  blocksize in [1, 65536], any value. */
+int mbnb_quantize_blockwise(const void *A, int dtype, int64_t numel, int blocksize,
+                            const float *absmax_in, int8_t *out, float *absmax_out, void *stream);
+
+/* dequantize_blockwise — functional.py:542-600. */
+int mbnb_dequantize_blockwise(const int8_t *q, int64_t numel, const float *absmax, int blocksize,
+                              int out_dtype, void *out, void *stream);
+
+/* quantize_rowwise — functional.py:607-625; scales[r] = clamp(max|row|, 1e-8) (NOT /127). */
+int mbnb_quantize_rowwise(const void *A, int dtype, int64_t rows, int64_t cols, int8_t *out,
+                          float *scales, void *stream);
+
+/* dequantize_rowwise — functional.py:628-636. */
+int mbnb_dequantize_rowwise(const int8_t *q, const float *scales, int64_t rows, int64_t cols,
+                            int out_dtype, void *out, void *stream);
+
+/* double_quant — functional.py:814-863 (LLM.int8 row + column statistics; dead native binding
+ * `_C.double_quant`, mm:2271-2303, is a different format and is not reproduced).
+ * col_given / row_given: the stats buffers already hold caller-supplied statistics. */
+int mbnb_double_quant(const void *A, int dtype, int64_t rows, int64_t cols, int8_t *out_col,
+                      int8_t *out_row, float *col_stats, float *row_stats, int col_given,
+                      int row_given, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * matmul_4bit — replaces `_C.matmul_nf4` / `_C.matmul_fp4`
+ * (mm:1956-2032, :2099-2151, bindings :2741-2751; call sites functional.py:743,745)
+ * with the numerics of the reference's CPU branch (functional.py:752-773):
+ *   out[M,N] = cast_out( round_w( A[M,K] · dequant(W)[N,K]^T + bias[N] ) )
+ * where dequant(W) is rounded to `w_dtype` (= QuantState.dtype) before the
+ * contraction (functional.py:382), A and bias are given in `w_dtype`, products
+ * accumulate in f32, the sum is rounded once to `w_dtype` and then cast to `out_dtype`.
+ *   packed  u8 [N, K_weight/2]; absmax covers [N, K_weight/blocksize]
+ *   K       activation width (= QuantState.shape[1]); K_weight >= K is the padded row length
+ *   bias    optional [N] of w_dtype
+ * Dispatch: M <= 16 -> wave-per-row GEMV (HBM-bound); larger M -> LDS-tiled MFMA GEMM
+ * with the dequant fused in the B-tile producer; odd layouts -> generic kernel.
+ * ------------------------------------------------------------------------- */
+int mbnb_matmul_4bit(const void *A, int64_t M, int64_t K, const uint8_t *packed,
+                     const mbnb_absmax *absmax, int64_t N, int64_t K_weight, int blocksize,
+                     int quant_type, int w_dtype, const void *bias, int out_dtype, void *out,
+                     void *stream);
+
+/* ---------------------------------------------------------------------------
+ * matmul_int8 — replaces `_C.matmul_int8` (mm:1789-1834, kernel mm:155-196) /
+ * functional.matmul_int8 (functional.py:788-793):
+ *   out[M,N] = cast( int32(A[M,K] · B[K,N]) * (A_scales[m]/127) * (B_scales[n]/127) )
+ * on the int8 MFMA.  `workspace` must hold N*K bytes (B is re-laid out K-contiguous);
+ * it may be reused as soon as the call's work has completed on `stream`.
+ * ------------------------------------------------------------------------- */
+int mbnb_matmul_int8(const int8_t *A, const int8_t *B, const float *A_scales,
+                     const float *B_scales, int64_t M, int64_t N, int64_t K, int out_dtype,
+                     void *out, void *workspace, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * linear_int8 — replaces `_C.linear_int8` (mm:1836-1886, kernel mm:203-305) with the numerics
+ * of Linear8bit.forward (nn/linear8bit.py:70-102):
+ *   out[M,N] = X[M,K] · round_dtype(W_i8[N,K] * (scales[n]/127))^T + bias[N]
+ * X, bias, out in `dtype` (f16 / bf16 / f32); f32 accumulation; one rounding.
+ * ------------------------------------------------------------------------- */
+int mbnb_linear_int8(const void *X, int dtype, int64_t M, int64_t K, const int8_t *W,
+                     const float *W_scales, int64_t N, const void *bias, void *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MBNB_HIP_H */

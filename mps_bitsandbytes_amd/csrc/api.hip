@@ -1,0 +1,194 @@
+// api.hip — extern "C" entry points declared in include/mbnb_hip.h: argument validation,
+// status / error-string convention, dispatch to the kernel launchers.  No device allocation,
+// no synchronisation, no mutable global state (thread-local error text only).
+#include <cstdarg>
+#include <cstdio>
+
+#include "common.h"
+
+namespace mbnb {
+
+static thread_local char g_err[512] = "";
+static thread_local const char *g_kernel = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+void set_kernel_name(const char *name) { g_kernel = name; }
+
+int check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: kernel launch failed: %s", what, hipGetErrorString(e));
+        return (int)e;
+    }
+    return MBNB_OK;
+}
+
+// launchers (quant_kernels.hip, matmul4_kernels.hip, int8_kernels.hip)
+int quantize_4bit_dispatch(const void *, int, int64_t, int64_t, int64_t, int, int, const float *, uint8_t *, float *, hipStream_t);
+int dequantize_4bit_dispatch(const uint8_t *, const AbsmaxView &, int64_t, int64_t, int64_t, int, int, int, void *, hipStream_t);
+int quantize_blockwise_dispatch(const void *, int, int64_t, int, const float *, int8_t *, float *, hipStream_t);
+int dequantize_blockwise_dispatch(const int8_t *, int64_t, const float *, int, int, void *, hipStream_t);
+int quantize_rowwise_dispatch(const void *, int, int64_t, int64_t, int8_t *, float *, hipStream_t);
+int dequantize_rowwise_dispatch(const int8_t *, const float *, int64_t, int64_t, int, void *, hipStream_t);
+int double_quant_dispatch(const void *, int, int64_t, int64_t, int8_t *, int8_t *, float *, float *, int, int, hipStream_t);
+int matmul_4bit_dispatch(const void *, int64_t, int64_t, const uint8_t *, const AbsmaxView &, int64_t, int64_t, int, int, int, const void *, int, void *, hipStream_t);
+int matmul_int8_dispatch(const int8_t *, const int8_t *, const float *, const float *, int64_t, int64_t, int64_t, int, void *, void *, hipStream_t);
+int linear_int8_dispatch(const void *, int, int64_t, int64_t, const int8_t *, const float *, int64_t, const void *, void *, hipStream_t);
+
+static bool dtype_ok(int d) { return d == MBNB_F16 || d == MBNB_BF16 || d == MBNB_F32; }
+static bool qt_ok(int q) { return q == MBNB_NF4 || q == MBNB_FP4; }
+static bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+static int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+static int absmax_view(const mbnb_absmax *a, const char *who, AbsmaxView &v) {
+    if (!a) return fail(MBNB_ERR_ARG, "%s: absmax descriptor is NULL", who);
+    if (a->absmax_i8) {
+        if (!a->absmax2 || a->blocksize2 <= 0)
+            return fail(MBNB_ERR_ARG, "%s: int8 absmax needs absmax2 and blocksize2 > 0", who);
+        v = AbsmaxView{nullptr, a->absmax_i8, a->absmax2, a->blocksize2};
+    } else {
+        if (!a->absmax_f32) return fail(MBNB_ERR_ARG, "%s: absmax_f32 and absmax_i8 are both NULL", who);
+        v = AbsmaxView{a->absmax_f32, nullptr, nullptr, 1};
+    }
+    return MBNB_OK;
+}
+
+}  // namespace mbnb
+
+using namespace mbnb;
+
+extern "C" {
+
+int mbnb_abi_version(void) { return MBNB_ABI_VERSION; }
+const char *mbnb_last_error(void) { return g_err; }
+const char *mbnb_last_kernel(void) { return g_kernel; }
+
+int mbnb_quantize_4bit(const void *A, int dtype, int64_t rows, int64_t cols, int64_t cols_padded, int blocksize,
+                       int quant_type, const float *absmax_in, uint8_t *packed, float *absmax_out, void *stream) {
+    if (!dtype_ok(dtype) || !qt_ok(quant_type)) return fail(MBNB_ERR_ARG, "quantize_4bit: bad dtype/quant_type");
+    if (rows < 0 || cols < 0) return fail(MBNB_ERR_ARG, "quantize_4bit: negative size");
+    if (!pow2(blocksize) || blocksize > 65536)
+        return fail(MBNB_ERR_ARG, "quantize_4bit: blocksize must be a power of 2 in [1, 65536], got %d", blocksize);
+    if (cols_padded < cols || cols_padded % blocksize || cols_padded % 2)
+        return fail(MBNB_ERR_SHAPE, "quantize_4bit: cols_padded=%lld inconsistent with cols=%lld blocksize=%d",
+                    (long long)cols_padded, (long long)cols, blocksize);
+    if (rows == 0 || cols_padded == 0) return MBNB_OK;
+    if (!A || !packed || !absmax_out) return fail(MBNB_ERR_ARG, "quantize_4bit: NULL pointer");
+    if (reinterpret_cast<uintptr_t>(packed) & 3) return fail(MBNB_ERR_ARG, "quantize_4bit: packed must be 4-byte aligned");
+    return quantize_4bit_dispatch(A, dtype, rows, cols, cols_padded, blocksize, quant_type, absmax_in, packed,
+                                  absmax_out, static_cast<hipStream_t>(stream));
+}
+
+int mbnb_dequantize_4bit(const uint8_t *packed, const mbnb_absmax *absmax, int64_t rows, int64_t cols,
+                         int64_t cols_padded, int blocksize, int quant_type, int out_dtype, void *out, void *stream) {
+    if (!dtype_ok(out_dtype) || !qt_ok(quant_type)) return fail(MBNB_ERR_ARG, "dequantize_4bit: bad dtype/quant_type");
+    if (rows < 0 || cols < 0) return fail(MBNB_ERR_ARG, "dequantize_4bit: negative size");
+    if (!pow2(blocksize) || blocksize > 65536) return fail(MBNB_ERR_ARG, "dequantize_4bit: bad blocksize %d", blocksize);
+    if (cols_padded < cols || cols_padded % blocksize || cols_padded % 2)
+        return fail(MBNB_ERR_SHAPE, "dequantize_4bit: cols_padded inconsistent");
+    if (rows == 0 || cols == 0) return MBNB_OK;
+    AbsmaxView v;
+    if (int rc = absmax_view(absmax, "dequantize_4bit", v)) return rc;
+    if (!packed || !out) return fail(MBNB_ERR_ARG, "dequantize_4bit: NULL pointer");
+    if (reinterpret_cast<uintptr_t>(packed) & 3) return fail(MBNB_ERR_ARG, "dequantize_4bit: packed must be 4-byte aligned");
+    return dequantize_4bit_dispatch(packed, v, rows, cols, cols_padded, blocksize, quant_type, out_dtype, out,
+                                    static_cast<hipStream_t>(stream));
+}
+
+int mbnb_quantize_blockwise(const void *A, int dtype, int64_t numel, int blocksize, const float *absmax_in,
+                            int8_t *out, float *absmax_out, void *stream) {
+    if (!dtype_ok(dtype)) return fail(MBNB_ERR_ARG, "quantize_blockwise: bad dtype");
+    if (numel < 0 || blocksize <= 0 || blocksize > 65536) return fail(MBNB_ERR_ARG, "quantize_blockwise: bad size");
+    if (numel == 0) return MBNB_OK;
+    if (!A || !out || !absmax_out) return fail(MBNB_ERR_ARG, "quantize_blockwise: NULL pointer");
+    return quantize_blockwise_dispatch(A, dtype, numel, blocksize, absmax_in, out, absmax_out,
+                                       static_cast<hipStream_t>(stream));
+}
+
+int mbnb_dequantize_blockwise(const int8_t *q, int64_t numel, const float *absmax, int blocksize, int out_dtype,
+                              void *out, void *stream) {
+    if (!dtype_ok(out_dtype)) return fail(MBNB_ERR_ARG, "dequantize_blockwise: bad dtype");
+    if (numel < 0 || blocksize <= 0) return fail(MBNB_ERR_ARG, "dequantize_blockwise: bad size");
+    if (numel == 0) return MBNB_OK;
+    if (!q || !absmax || !out) return fail(MBNB_ERR_ARG, "dequantize_blockwise: NULL pointer");
+    return dequantize_blockwise_dispatch(q, numel, absmax, blocksize, out_dtype, out, static_cast<hipStream_t>(stream));
+}
+
+int mbnb_quantize_rowwise(const void *A, int dtype, int64_t rows, int64_t cols, int8_t *out, float *scales,
+                          void *stream) {
+    if (!dtype_ok(dtype)) return fail(MBNB_ERR_ARG, "quantize_rowwise: bad dtype");
+    if (rows < 0 || cols < 0) return fail(MBNB_ERR_ARG, "quantize_rowwise: negative size");
+    if (rows == 0) return MBNB_OK;
+    if (!A || !out || !scales) return fail(MBNB_ERR_ARG, "quantize_rowwise: NULL pointer");
+    return quantize_rowwise_dispatch(A, dtype, rows, cols, out, scales, static_cast<hipStream_t>(stream));
+}
+
+int mbnb_dequantize_rowwise(const int8_t *q, const float *scales, int64_t rows, int64_t cols, int out_dtype,
+                            void *out, void *stream) {
+    if (!dtype_ok(out_dtype)) return fail(MBNB_ERR_ARG, "dequantize_rowwise: bad dtype");
+    if (rows < 0 || cols < 0) return fail(MBNB_ERR_ARG, "dequantize_rowwise: negative size");
+    if (rows == 0 || cols == 0) return MBNB_OK;
+    if (!q || !scales || !out) return fail(MBNB_ERR_ARG, "dequantize_rowwise: NULL pointer");
+    return dequantize_rowwise_dispatch(q, scales, rows, cols, out_dtype, out, static_cast<hipStream_t>(stream));
+}
+
+int mbnb_double_quant(const void *A, int dtype, int64_t rows, int64_t cols, int8_t *out_col, int8_t *out_row,
+                      float *col_stats, float *row_stats, int col_given, int row_given, void *stream) {
+    if (!dtype_ok(dtype)) return fail(MBNB_ERR_ARG, "double_quant: bad dtype");
+    if (rows < 0 || cols < 0) return fail(MBNB_ERR_ARG, "double_quant: negative size");
+    if (rows == 0 || cols == 0) return MBNB_OK;
+    if (!A || !out_col || !out_row || !col_stats || !row_stats) return fail(MBNB_ERR_ARG, "double_quant: NULL pointer");
+    return double_quant_dispatch(A, dtype, rows, cols, out_col, out_row, col_stats, row_stats, col_given, row_given,
+                                 static_cast<hipStream_t>(stream));
+}
+
+int mbnb_matmul_4bit(const void *A, int64_t M, int64_t K, const uint8_t *packed, const mbnb_absmax *absmax, int64_t N,
+                     int64_t K_weight, int blocksize, int quant_type, int w_dtype, const void *bias, int out_dtype,
+                     void *out, void *stream) {
+    if (!dtype_ok(w_dtype) || !dtype_ok(out_dtype) || !qt_ok(quant_type))
+        return fail(MBNB_ERR_ARG, "matmul_4bit: bad dtype/quant_type");
+    if (M < 0 || N < 0 || K < 0) return fail(MBNB_ERR_ARG, "matmul_4bit: negative size");
+    if (!pow2(blocksize) || blocksize > 65536) return fail(MBNB_ERR_ARG, "matmul_4bit: bad blocksize %d", blocksize);
+    if (K_weight < K || K_weight % blocksize || K_weight % 2)
+        return fail(MBNB_ERR_SHAPE, "matmul_4bit: K_weight=%lld inconsistent with K=%lld blocksize=%d",
+                    (long long)K_weight, (long long)K, blocksize);
+    if (M == 0 || N == 0) return MBNB_OK;
+    AbsmaxView v;
+    if (int rc = absmax_view(absmax, "matmul_4bit", v)) return rc;
+    if (!A || !packed || !out) return fail(MBNB_ERR_ARG, "matmul_4bit: NULL pointer");
+    return matmul_4bit_dispatch(A, M, K, packed, v, N, K_weight, blocksize, quant_type, w_dtype, bias, out_dtype, out,
+                                static_cast<hipStream_t>(stream));
+}
+
+int mbnb_matmul_int8(const int8_t *A, const int8_t *B, const float *A_scales, const float *B_scales, int64_t M,
+                     int64_t N, int64_t K, int out_dtype, void *out, void *workspace, void *stream) {
+    if (!dtype_ok(out_dtype)) return fail(MBNB_ERR_ARG, "matmul_int8: bad dtype");
+    if (M < 0 || N < 0 || K < 0) return fail(MBNB_ERR_ARG, "matmul_int8: negative size");
+    if (M == 0 || N == 0) return MBNB_OK;
+    if (!A || !B || !A_scales || !B_scales || !out) return fail(MBNB_ERR_ARG, "matmul_int8: NULL pointer");
+    return matmul_int8_dispatch(A, B, A_scales, B_scales, M, N, K, out_dtype, out, workspace,
+                                static_cast<hipStream_t>(stream));
+}
+
+int mbnb_linear_int8(const void *X, int dtype, int64_t M, int64_t K, const int8_t *W, const float *W_scales, int64_t N,
+                     const void *bias, void *out, void *stream) {
+    if (!dtype_ok(dtype)) return fail(MBNB_ERR_ARG, "linear_int8: bad dtype");
+    if (M < 0 || N < 0 || K < 0) return fail(MBNB_ERR_ARG, "linear_int8: negative size");
+    if (M == 0 || N == 0) return MBNB_OK;
+    if (!X || !W || !W_scales || !out) return fail(MBNB_ERR_ARG, "linear_int8: NULL pointer");
+    return linear_int8_dispatch(X, dtype, M, K, W, W_scales, N, bias, out, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,139 @@
+// common.h — shared device/host helpers for the gfx950 kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mbnb_hip.h"
+
+namespace mbnb {
+
+// ---------------------------------------------------------------- element types
+using f16_t = _Float16;
+using bf16_t = __bf16;
+
+template <int DT> struct ElemT;
+template <> struct ElemT<MBNB_F16> { using type = f16_t; };
+template <> struct ElemT<MBNB_BF16> { using type = bf16_t; };
+template <> struct ElemT<MBNB_F32> { using type = float; };
+
+template <typename T> __device__ __forceinline__ float to_f32(T v) { return (float)v; }
+// RNE conversions: plain casts lower to v_cvt_f16_f32 / v_cvt_pk_bf16_f32 on gfx950.
+template <typename T> __device__ __forceinline__ T from_f32(float v) { return (T)v; }
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+typedef f16_t f16x8 __attribute__((ext_vector_type(8)));
+typedef bf16_t bf16x8 __attribute__((ext_vector_type(8)));
+typedef f16_t f16x2 __attribute__((ext_vector_type(2)));
+typedef bf16_t bf16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+
+// pack two f32 into one dword of two 16-bit values (RNE), element 0 in the low half
+template <typename T> __device__ __forceinline__ uint32_t pack2(float lo, float hi);
+template <> __device__ __forceinline__ uint32_t pack2<f16_t>(float lo, float hi) {
+    f16x2 v = {(f16_t)lo, (f16_t)hi};
+    return __builtin_bit_cast(uint32_t, v);
+}
+template <> __device__ __forceinline__ uint32_t pack2<bf16_t>(float lo, float hi) {
+    bf16x2 v = {(bf16_t)lo, (bf16_t)hi};
+    return __builtin_bit_cast(uint32_t, v);
+}
+
+template <typename T> __device__ __forceinline__ float unpack_lo(uint32_t w);
+template <typename T> __device__ __forceinline__ float unpack_hi(uint32_t w);
+template <> __device__ __forceinline__ float unpack_lo<f16_t>(uint32_t w) {
+    return (float)__builtin_bit_cast(f16x2, w)[0];
+}
+template <> __device__ __forceinline__ float unpack_hi<f16_t>(uint32_t w) {
+    return (float)__builtin_bit_cast(f16x2, w)[1];
+}
+template <> __device__ __forceinline__ float unpack_lo<bf16_t>(uint32_t w) {
+    return __builtin_bit_cast(float, w << 16);
+}
+template <> __device__ __forceinline__ float unpack_hi<bf16_t>(uint32_t w) {
+    return __builtin_bit_cast(float, w & 0xFFFF0000u);
+}
+
+// ---------------------------------------------------------------- code tables (functional.py:21-32)
+__device__ __forceinline__ float nf4_code(int i) {
+    constexpr float t[16] = {-1.0f, -0.6961928009986877f, -0.5250730514526367f, -0.39491748809814453f,
+                             -0.28444138169288635f, -0.18477343022823334f, -0.09105003625154495f, 0.0f,
+                             0.07958029955625534f, 0.16093020141124725f, 0.24611230194568634f,
+                             0.33791524171829224f, 0.44070982933044434f, 0.5626170039176941f,
+                             0.7229568362236023f, 1.0f};
+    return t[i];
+}
+__device__ __forceinline__ float fp4_code(int i) {
+    constexpr float t[16] = {0.0f, 0.0625f, 0.125f, 0.25f, 0.375f, 0.5f, 0.75f, 1.0f,
+                             -0.0f, -0.0625f, -0.125f, -0.25f, -0.375f, -0.5f, -0.75f, -1.0f};
+    return t[i];
+}
+template <int QT> __device__ __forceinline__ float code_value(int i) {
+    return QT == MBNB_NF4 ? nf4_code(i) : fp4_code(i);
+}
+
+// Fill a 16-entry LDS table with the code values (one lane per entry).
+template <int QT> __device__ __forceinline__ void fill_code_lut(float *lut, int tid) {
+    if (tid < 16) {
+        float v = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            if (tid == i) v = code_value<QT>(i);
+        lut[tid] = v;
+    }
+}
+
+// ---------------------------------------------------------------- absmax decode
+struct AbsmaxView {
+    const float *f32;
+    const int8_t *i8;
+    const float *am2;
+    int bs2;
+};
+
+// absmax[i]; for the double-quantised form this is dequantize_blockwise's arithmetic
+// (functional.py:592-594): q.float() * (absmax2 / 127.0)  -- true division, then one multiply.
+template <bool NESTED> __device__ __forceinline__ float load_absmax(const AbsmaxView &a, int64_t i) {
+    if constexpr (NESTED) {
+        float s = a.am2[i / a.bs2] / 127.0f;
+        return (float)a.i8[i] * s;
+    } else {
+        return a.f32[i];
+    }
+}
+
+// `127.0 / tensor` in the reference is evaluated by torch as reciprocal(tensor) * 127.0
+// (Python scalar / Tensor -> Tensor.__rtruediv__): two roundings.  See oracle/oracle.c rscale127.
+__device__ __forceinline__ float rscale127(float absmax) {
+    float r = 1.0f / absmax;  // correctly rounded (no fast-math)
+    return r * 127.0f;
+}
+
+__device__ __forceinline__ int8_t quant_i8(float x, float scale) {
+    float q = rintf(x * scale);  // torch.round = half-to-even
+    q = fminf(fmaxf(q, -127.0f), 127.0f);
+    return (int8_t)(int)q;
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------- host side
+void set_error(const char *fmt, ...);
+void set_kernel_name(const char *name);
+int check_launch(const char *what);
+
+}  // namespace mbnb

@@ -1,0 +1,245 @@
+// int8_kernels.hip — rowwise-INT8 matmuls for gfx950.
+//
+//   matmul_int8  int8 x int8 -> int32 on v_mfma_i32_32x32x32_i8, epilogue acc*(sA[m]/127)*(sB[n]/127)
+//                (reference: functional.py:788-793; Metal kernel int8_matmul_dequant mm:155-196)
+//   linear_int8  16-bit activations x int8 weights decoded in the B-tile producer (gemm_tile.h)
+//                (reference: Linear8bit.forward nn/linear8bit.py:70-102; Metal int8_matmul_simd mm:203-305)
+#include "gemm_tile.h"
+
+namespace mbnb {
+
+// ------------------------------------------------------------------ B[K,N] -> Bt[N,K] (bytes)
+__global__ __launch_bounds__(256) void k_transpose_i8(const int8_t *__restrict__ B, int8_t *__restrict__ Bt, int64_t K,
+                                                     int64_t N) {
+    __shared__ int8_t tile[64][65];
+    const int64_t k0 = (int64_t)blockIdx.y * 64, n0 = (int64_t)blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int64_t k = k0 + i, n = n0 + tx;
+        tile[i][tx] = (k < K && n < N) ? B[k * N + n] : (int8_t)0;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int64_t n = n0 + i, k = k0 + tx;
+        if (n < N && k < K) Bt[n * K + k] = tile[tx][i];
+    }
+}
+
+// ------------------------------------------------------------------ int8 x int8 MFMA GEMM
+// Tile 128 x 128 x 128(k, int8) -> the same 128-byte-row swizzled LDS images as gemm_tile.h.
+// Orientation as there: Bt rows (n) are the MFMA "A" operand, A rows (m) the "B" operand.
+template <typename OutT>
+__global__ __launch_bounds__(256, 2) void k_gemm_i8(const int8_t *__restrict__ A, const int8_t *__restrict__ Bt,
+                                                    const float *__restrict__ sA, const float *__restrict__ sB,
+                                                    OutT *__restrict__ out, int64_t M, int64_t N, int64_t K) {
+    constexpr int BM = 128, BN = 128, BK8 = 128;
+    constexpr int A_BYTES = BM * ROW_BYTES, B_BYTES = BN * ROW_BYTES, STAGE = A_BYTES + B_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave >> 1, wm = wave & 1;
+    const int64_t tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    const int64_t nwg = tiles_m * tiles_n;
+    int64_t bid = blockIdx.x;
+    {
+        const int64_t q = nwg / 8, r = nwg % 8, xcd = bid % 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+    }
+    const int64_t m0 = (bid % tiles_m) * BM, n0 = (bid / tiles_m) * BN;
+    const int chunk = tid & 7, row = tid >> 3;
+
+    u32x4 a_regs[4], b_regs[4];
+    auto fetch_tile = [&](int64_t k0) {
+        const int64_t k = k0 + chunk * 16;
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const int64_t m = m0 + row + 32 * p, n = n0 + row + 32 * p;
+            a_regs[p] = (m < M && k + 16 <= K) ? *reinterpret_cast<const u32x4 *>(A + m * K + k) : u32x4{0, 0, 0, 0};
+            b_regs[p] = (n < N && k + 16 <= K) ? *reinterpret_cast<const u32x4 *>(Bt + n * K + k) : u32x4{0, 0, 0, 0};
+        }
+    };
+    auto stage_tile = [&](int buf) {
+        char *As = smem + buf * STAGE, *Bs = As + A_BYTES;
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            *reinterpret_cast<u32x4 *>(As + swz_off(row + 32 * p, chunk)) = a_regs[p];
+            *reinterpret_cast<u32x4 *>(Bs + swz_off(row + 32 * p, chunk)) = b_regs[p];
+        }
+    };
+    i32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0;
+
+    const int64_t nk = (K + BK8 - 1) / BK8;
+    fetch_tile(0);
+    stage_tile(0);
+    const int fr = lane & 31, fh = lane >> 5;
+    for (int64_t kt = 0; kt < nk; kt++) {
+        const int buf = (int)(kt & 1);
+        __syncthreads();
+        if (kt + 1 < nk) fetch_tile((kt + 1) * BK8);
+        const char *As = smem + buf * STAGE, *Bs = As + A_BYTES;
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            i32x4 wf[2], xf[2];
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                wf[i] = *reinterpret_cast<const i32x4 *>(Bs + swz_off(wn * 64 + i * 32 + fr, 2 * s + fh));
+                xf[i] = *reinterpret_cast<const i32x4 *>(As + swz_off(wm * 64 + i * 32 + fr, 2 * s + fh));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[i], xf[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) stage_tile(buf ^ 1);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int64_t m = m0 + wm * 64 + j * 32 + fr;
+            if (m >= M) continue;
+            const float sa = sA[m] / 127.0f;
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int64_t n = n0 + wn * 64 + i * 32 + 8 * g + 4 * fh;
+                if (n >= N) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const float sb = (n + e < N) ? sB[n + e] / 127.0f : 0.0f;
+                    v[e] = (float)acc[i][j][4 * g + e] * sa * sb;
+                }
+                OutT *o = out + m * N + n;
+                if (n + 4 <= N && ((reinterpret_cast<uintptr_t>(o) & (4 * sizeof(OutT) - 1)) == 0)) {
+                    if constexpr (sizeof(OutT) == 2)
+                        *reinterpret_cast<u32x2 *>(o) = u32x2{pack2<OutT>(v[0], v[1]), pack2<OutT>(v[2], v[3])};
+                    else
+                        *reinterpret_cast<f32x4 *>(o) = f32x4{v[0], v[1], v[2], v[3]};
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        if (n + e < N) o[e] = from_f32<OutT>(v[e]);
+                }
+            }
+        }
+}
+
+// odd K (not a multiple of 16) or unaligned pointers: one wave per output element row
+template <typename OutT>
+__global__ __launch_bounds__(256) void k_matmul_i8_generic(const int8_t *__restrict__ A, const int8_t *__restrict__ B,
+                                                          const float *__restrict__ sA, const float *__restrict__ sB,
+                                                          OutT *__restrict__ out, int64_t M, int64_t N, int64_t K) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * N) return;
+    const int64_t m = i / N, n = i % N;
+    int acc = 0;
+    for (int64_t k = 0; k < K; k++) acc += (int)A[m * K + k] * (int)B[k * N + n];
+    out[i] = from_f32<OutT>((float)acc * (sA[m] / 127.0f) * (sB[n] / 127.0f));
+}
+
+int matmul_int8_dispatch(const int8_t *A, const int8_t *B, const float *sA, const float *sB, int64_t M, int64_t N,
+                         int64_t K, int out_dtype, void *out, void *workspace, hipStream_t st) {
+    const bool fast = (K % 16 == 0) && workspace != nullptr &&
+                      ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(workspace)) & 15) == 0;
+    if (!fast) {
+        const unsigned grid = (unsigned)((M * N + 255) / 256);
+        switch (out_dtype) {
+            case MBNB_F16: hipLaunchKernelGGL(k_matmul_i8_generic<f16_t>, dim3(grid), dim3(256), 0, st, A, B, sA, sB, static_cast<f16_t *>(out), M, N, K); break;
+            case MBNB_BF16: hipLaunchKernelGGL(k_matmul_i8_generic<bf16_t>, dim3(grid), dim3(256), 0, st, A, B, sA, sB, static_cast<bf16_t *>(out), M, N, K); break;
+            default: hipLaunchKernelGGL(k_matmul_i8_generic<float>, dim3(grid), dim3(256), 0, st, A, B, sA, sB, static_cast<float *>(out), M, N, K); break;
+        }
+        set_kernel_name("i8_generic");
+        return check_launch("matmul_int8(generic)");
+    }
+    int8_t *Bt = static_cast<int8_t *>(workspace);
+    hipLaunchKernelGGL(k_transpose_i8, dim3((unsigned)((N + 63) / 64), (unsigned)((K + 63) / 64)), dim3(256), 0, st, B, Bt, K, N);
+    const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
+    constexpr int lds = 2 * (128 + 128) * ROW_BYTES;
+#define MBNB_I8(OT)                                                                                                  \
+    do {                                                                                                             \
+        auto kern = k_gemm_i8<OT>;                                                                                   \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                     \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);                         \
+        if (e != hipSuccess) {                                                                                       \
+            set_error("matmul_int8: hipFuncSetAttribute failed: %s", hipGetErrorString(e));                          \
+            return (int)e;                                                                                           \
+        }                                                                                                            \
+        hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, st, A, Bt, sA, sB, static_cast<OT *>(out), M, N, K); \
+    } while (0)
+    switch (out_dtype) {
+        case MBNB_F16: MBNB_I8(f16_t); break;
+        case MBNB_BF16: MBNB_I8(bf16_t); break;
+        default: MBNB_I8(float); break;
+    }
+#undef MBNB_I8
+    set_kernel_name("i8_mfma128");
+    return check_launch("matmul_int8(mfma)");
+}
+
+// ------------------------------------------------------------------ linear_int8 (W8A16)
+template <typename T>
+__global__ __launch_bounds__(256) void k_linear_i8_generic(const T *__restrict__ X, const int8_t *__restrict__ W,
+                                                          const float *__restrict__ scales, const T *__restrict__ bias,
+                                                          T *__restrict__ out, int64_t M, int64_t N, int64_t K) {
+    const int lane = threadIdx.x & 63;
+    const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t m = blockIdx.y;
+    if (n >= N) return;
+    const float s = scales[n] / 127.0f;
+    float acc = 0.0f;
+    for (int64_t k = lane; k < K; k += 64) {
+        const float w = to_f32(from_f32<T>((float)W[n * K + k] * s));
+        acc = fmaf(to_f32(X[m * K + k]), w, acc);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) out[m * N + n] = from_f32<T>(acc + (bias ? to_f32(bias[n]) : 0.0f));
+}
+
+template <typename T>
+static int launch_linear_int8(const void *X, int64_t M, int64_t K, const int8_t *W, const float *scales, int64_t N,
+                              const void *bias, void *out, hipStream_t st) {
+    const T *x = static_cast<const T *>(X);
+    const T *b = static_cast<const T *>(bias);
+    T *o = static_cast<T *>(out);
+    if constexpr (sizeof(T) == 2) {
+        const bool fast = (K % 16 == 0) && (((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(W)) & 15) == 0) && M > 4;
+        if (fast) {
+            using P = I8Producer<T>;
+            typename P::Params wp{W, scales, N, K};
+            constexpr int BM = 128, BN = 128;
+            constexpr int lds = gemm_decode_lds_bytes<BM, BN>();
+            auto kern = k_gemm_decode<T, T, P, BM, BN>;
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e != hipSuccess) {
+                set_error("linear_int8: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+                return (int)e;
+            }
+            const int64_t tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+            hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, st, x, wp, b, o, M, N, K);
+            set_kernel_name("w8a16_mfma128");
+            return check_launch("linear_int8(mfma)");
+        }
+    }
+    hipLaunchKernelGGL(k_linear_i8_generic<T>, dim3((unsigned)((N + 3) / 4), (unsigned)M), dim3(256), 0, st, x, W, scales,
+                       b, o, M, N, K);
+    set_kernel_name("w8a16_generic");
+    return check_launch("linear_int8(generic)");
+}
+
+int linear_int8_dispatch(const void *X, int dtype, int64_t M, int64_t K, const int8_t *W, const float *scales,
+                         int64_t N, const void *bias, void *out, hipStream_t st) {
+    switch (dtype) {
+        case MBNB_F16: return launch_linear_int8<f16_t>(X, M, K, W, scales, N, bias, out, st);
+        case MBNB_BF16: return launch_linear_int8<bf16_t>(X, M, K, W, scales, N, bias, out, st);
+        default: return launch_linear_int8<float>(X, M, K, W, scales, N, bias, out, st);
+    }
+}
+
+}  // namespace mbnb

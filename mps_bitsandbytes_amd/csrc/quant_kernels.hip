@@ -1,0 +1,508 @@
+// quant_kernels.hip — quantize / dequantize kernels (HBM-bound byte work) for gfx950.
+//
+// Bit-exact counterparts of the reference's pure-torch functions:
+//   quantize_4bit      functional.py:163-303      dequantize_4bit      functional.py:306-416
+//   quantize_blockwise functional.py:469-539      dequantize_blockwise functional.py:542-600
+//   quantize_rowwise   functional.py:607-625      dequantize_rowwise   functional.py:628-636
+//   double_quant       functional.py:814-863
+// Compiled with -ffp-contract=off: every f32 operation below is a single IEEE operation in
+// the order the reference performs it (division, not reciprocal-multiply, for x / absmax).
+#include "common.h"
+
+namespace mbnb {
+
+// =====================================================================================
+// quantize_4bit
+// Lane layout (blocksize >= 8): each lane owns 8 consecutive elements of a padded row
+// (16 B of fp16/bf16 in, 4 B of packed nibbles out); a quantisation block is owned by a
+// team of blocksize/8 consecutive lanes (team <= 64 lanes = one wave); for blocksize > 512
+// a wave walks the block in 512-element steps.  Coalesced: a wave reads 1 KiB and writes
+// 256 B per step.
+// =====================================================================================
+template <typename T>
+__device__ __forceinline__ void load8(const T *A, int64_t rows, int64_t cols, int64_t r, int64_t k0,
+                                      bool vec_ok, float (&x)[8]) {
+    if (vec_ok && k0 + 8 <= cols) {
+        if constexpr (sizeof(T) == 2) {
+            u32x4 v = *reinterpret_cast<const u32x4 *>(A + r * cols + k0);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                x[2 * j] = unpack_lo<T>(v[j]);
+                x[2 * j + 1] = unpack_hi<T>(v[j]);
+            }
+        } else {
+            f32x4 v0 = *reinterpret_cast<const f32x4 *>(A + r * cols + k0);
+            f32x4 v1 = *reinterpret_cast<const f32x4 *>(A + r * cols + k0 + 4);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                x[j] = v0[j];
+                x[4 + j] = v1[j];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; j++) x[j] = (k0 + j < cols) ? to_f32(A[r * cols + k0 + j]) : 0.0f;
+    }
+}
+
+template <int QT> __device__ __forceinline__ uint32_t nearest_code(float xn) {
+    // argmin_i |xn - code[i]| with first-minimum tie-break (functional.py:242-243; strict `<`)
+    uint32_t best = 0;
+    float bd = fabsf(xn - code_value<QT>(0));
+#pragma unroll
+    for (int i = 1; i < 16; i++) {
+        float d = fabsf(xn - code_value<QT>(i));
+        if (d < bd) {
+            bd = d;
+            best = i;
+        }
+    }
+    return best;
+}
+
+template <typename T, int QT>
+__global__ __launch_bounds__(256) void k_quantize_4bit(const T *__restrict__ A, int64_t rows, int64_t cols,
+                                                      int64_t cols_padded, int blocksize,
+                                                      const float *__restrict__ absmax_in,
+                                                      uint8_t *__restrict__ packed,
+                                                      float *__restrict__ absmax_out, bool vec_ok) {
+    // one wave handles `span` = max(blocksize, 512) consecutive padded elements of one row
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int span = blocksize > 512 ? blocksize : 512;
+    const int64_t spans_per_row = (cols_padded + span - 1) / span;
+    const int64_t total = rows * spans_per_row;
+    if (wave >= total) return;
+    const int64_t r = wave / spans_per_row;
+    const int64_t kspan = (wave % spans_per_row) * span;
+    const int64_t nblk = cols_padded / blocksize;
+
+    if (blocksize <= 512) {
+        const int team = blocksize >> 3;  // lanes per block (1..64)
+        const int64_t k0 = kspan + (int64_t)lane * 8;
+        const bool active = k0 < cols_padded;
+        float x[8];
+        if (active) load8<T>(A, rows, cols, r, k0, vec_ok, x);
+        else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) x[j] = 0.0f;
+        }
+        const int64_t blk = active ? k0 / blocksize : 0;
+        float am;
+        if (absmax_in) {
+            am = active ? absmax_in[r * nblk + blk] : 1.0f;
+        } else {
+            am = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 8; j++) am = fmaxf(am, fabsf(x[j]));
+            for (int off = 1; off < team; off <<= 1) am = fmaxf(am, __shfl_xor(am, off, 64));
+            am = fmaxf(am, 1e-8f);  // clamp(min=1e-8), functional.py:232
+        }
+        if (!active) return;
+        if ((lane & (team - 1)) == 0) absmax_out[r * nblk + blk] = am;
+        uint32_t w = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) w |= nearest_code<QT>(x[j] / am) << (4 * j);
+        *reinterpret_cast<uint32_t *>(packed + (r * cols_padded + k0) / 2) = w;
+    } else {
+        // block larger than one wave step: pass 1 absmax over the block, pass 2 quantise
+        const int64_t blk = kspan / blocksize;
+        float am;
+        if (absmax_in) {
+            am = absmax_in[r * nblk + blk];
+        } else {
+            am = 0.0f;
+            for (int s = 0; s < span; s += 512) {
+                float x[8];
+                load8<T>(A, rows, cols, r, kspan + s + lane * 8, vec_ok, x);
+#pragma unroll
+                for (int j = 0; j < 8; j++) am = fmaxf(am, fabsf(x[j]));
+            }
+            am = fmaxf(wave_max(am), 1e-8f);
+        }
+        if (lane == 0) absmax_out[r * nblk + blk] = am;
+        for (int s = 0; s < span; s += 512) {
+            const int64_t k0 = kspan + s + lane * 8;
+            float x[8];
+            load8<T>(A, rows, cols, r, k0, vec_ok, x);
+            uint32_t w = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) w |= nearest_code<QT>(x[j] / am) << (4 * j);
+            *reinterpret_cast<uint32_t *>(packed + (r * cols_padded + k0) / 2) = w;
+        }
+    }
+}
+
+// blocksize in {1, 2, 4}: one thread per output byte
+template <typename T, int QT>
+__global__ __launch_bounds__(256) void k_quantize_4bit_tiny(const T *__restrict__ A, int64_t rows, int64_t cols,
+                                                           int64_t cols_padded, int blocksize,
+                                                           const float *__restrict__ absmax_in,
+                                                           uint8_t *__restrict__ packed,
+                                                           float *__restrict__ absmax_out) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // byte index
+    const int64_t nbytes = rows * cols_padded / 2;
+    if (j >= nbytes) return;
+    const int64_t nblk = cols_padded / blocksize;
+    uint32_t byte = 0;
+    for (int e = 0; e < 2; e++) {
+        const int64_t flat = 2 * j + e;
+        const int64_t r = flat / cols_padded, k = flat % cols_padded;
+        const int64_t blk = k / blocksize;
+        float am;
+        if (absmax_in) am = absmax_in[r * nblk + blk];
+        else {
+            am = 0.0f;
+            for (int i = 0; i < blocksize; i++) {
+                int64_t kk = blk * blocksize + i;
+                am = fmaxf(am, kk < cols ? fabsf(to_f32(A[r * cols + kk])) : 0.0f);
+            }
+            am = fmaxf(am, 1e-8f);
+        }
+        if (k % blocksize == 0) absmax_out[r * nblk + blk] = am;
+        float x = k < cols ? to_f32(A[r * cols + k]) : 0.0f;
+        byte |= nearest_code<QT>(x / am) << (4 * e);
+    }
+    packed[j] = (uint8_t)byte;
+}
+
+// =====================================================================================
+// dequantize_4bit: each lane decodes one packed dword (8 elements): value = code[idx] *
+// absmax (f32), cast to the output dtype (RNE).  functional.py:360-382.
+// =====================================================================================
+template <typename T, int QT, bool NESTED>
+__global__ __launch_bounds__(256) void k_dequantize_4bit(const uint8_t *__restrict__ packed, AbsmaxView am,
+                                                        int64_t rows, int64_t cols, int64_t cols_padded,
+                                                        int blocksize, T *__restrict__ out, bool vec_ok) {
+    __shared__ float lut[16];
+    fill_code_lut<QT>(lut, threadIdx.x);
+    __syncthreads();
+    const int64_t groups_per_row = (cols + 7) / 8;
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= rows * groups_per_row) return;
+    const int64_t r = g / groups_per_row;
+    const int64_t k0 = (g % groups_per_row) * 8;
+    const int64_t nblk = cols_padded / blocksize;
+    const int64_t flat0 = r * cols_padded + k0;  // even (cols_padded even, k0 multiple of 8)
+    float v[8];
+    if ((cols_padded & 7) == 0) {
+        const uint32_t w = *reinterpret_cast<const uint32_t *>(packed + flat0 / 2);
+        if (blocksize >= 8) {
+            const float a = load_absmax<NESTED>(am, r * nblk + k0 / blocksize);
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = lut[(w >> (4 * j)) & 15] * a;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                v[j] = lut[(w >> (4 * j)) & 15] * load_absmax<NESTED>(am, r * nblk + (k0 + j) / blocksize);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int64_t k = k0 + j;
+            if (k < cols) {
+                const uint8_t b = packed[(flat0 + j) / 2];
+                const int idx = ((flat0 + j) & 1) ? (b >> 4) : (b & 15);
+                v[j] = lut[idx] * load_absmax<NESTED>(am, r * nblk + k / blocksize);
+            } else v[j] = 0.0f;
+        }
+    }
+    T *o = out + r * cols + k0;
+    if (vec_ok && k0 + 8 <= cols) {
+        if constexpr (sizeof(T) == 2) {
+            u32x4 p;
+#pragma unroll
+            for (int j = 0; j < 4; j++) p[j] = pack2<T>(v[2 * j], v[2 * j + 1]);
+            *reinterpret_cast<u32x4 *>(o) = p;
+        } else {
+            *reinterpret_cast<f32x4 *>(o) = f32x4{v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4 *>(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if (k0 + j < cols) o[j] = from_f32<T>(v[j]);
+    }
+}
+
+// =====================================================================================
+// quantize_blockwise / dequantize_blockwise (int8, flat blocks)
+// =====================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void k_quantize_blockwise(const T *__restrict__ A, int64_t numel, int blocksize,
+                                                           const float *__restrict__ absmax_in,
+                                                           int8_t *__restrict__ out,
+                                                           float *__restrict__ absmax_out) {
+    __shared__ float red[4];
+    const int64_t b = blockIdx.x;
+    const int64_t i0 = b * blocksize;
+    const int64_t i1 = (i0 + blocksize < numel) ? i0 + blocksize : numel;
+    float am;
+    if (absmax_in) am = absmax_in[b];
+    else {
+        am = 0.0f;
+        for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) am = fmaxf(am, fabsf(to_f32(A[i])));
+        am = wave_max(am);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = am;
+        __syncthreads();
+        am = fmaxf(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])), 1e-8f);
+    }
+    if (threadIdx.x == 0) absmax_out[b] = am;
+    const float scale = rscale127(am);  // functional.py:518
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) out[i] = quant_i8(to_f32(A[i]), scale);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_dequantize_blockwise(const int8_t *__restrict__ q, int64_t numel,
+                                                             const float *__restrict__ absmax, int blocksize,
+                                                             T *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= numel) return;
+    const float scale = absmax[i / blocksize] / 127.0f;  // functional.py:592
+    out[i] = from_f32<T>((float)q[i] * scale);
+}
+
+// =====================================================================================
+// quantize_rowwise: one workgroup per row (pass 1 absmax, pass 2 quantise; the row stays in L2)
+// =====================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void k_quantize_rowwise(const T *__restrict__ A, int64_t rows, int64_t cols,
+                                                         int8_t *__restrict__ out, float *__restrict__ scales,
+                                                         bool vec_ok) {
+    __shared__ float red[4];
+    const int64_t r = blockIdx.x;
+    const T *row = A + r * cols;
+    float am = 0.0f;
+    const int64_t nvec = vec_ok ? cols / 8 : 0;
+    for (int64_t g = threadIdx.x; g < nvec; g += 256) {
+        float x[8];
+        load8<T>(A, rows, cols, r, g * 8, true, x);
+#pragma unroll
+        for (int j = 0; j < 8; j++) am = fmaxf(am, fabsf(x[j]));
+    }
+    for (int64_t c = nvec * 8 + threadIdx.x; c < cols; c += 256) am = fmaxf(am, fabsf(to_f32(row[c])));
+    am = wave_max(am);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = am;
+    __syncthreads();
+    am = fmaxf(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])), 1e-8f);
+    if (threadIdx.x == 0) scales[r] = am;  // the absmax itself, functional.py:617-618
+    const float s = rscale127(am);         // functional.py:621
+    int8_t *orow = out + r * cols;
+    for (int64_t g = threadIdx.x; g < nvec; g += 256) {
+        float x[8];
+        load8<T>(A, rows, cols, r, g * 8, true, x);
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            lo |= (uint32_t)(uint8_t)quant_i8(x[j], s) << (8 * j);
+            hi |= (uint32_t)(uint8_t)quant_i8(x[4 + j], s) << (8 * j);
+        }
+        *reinterpret_cast<u32x2 *>(orow + g * 8) = u32x2{lo, hi};
+    }
+    for (int64_t c = nvec * 8 + threadIdx.x; c < cols; c += 256) orow[c] = quant_i8(to_f32(row[c]), s);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_dequantize_rowwise(const int8_t *__restrict__ q,
+                                                           const float *__restrict__ scales, int64_t rows,
+                                                           int64_t cols, T *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols) return;
+    const float s = scales[i / cols] / 127.0f;  // functional.py:635
+    out[i] = from_f32<T>((float)q[i] * s);
+}
+
+// =====================================================================================
+// double_quant (LLM.int8 row + column statistics)
+// =====================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void k_row_absmax(const T *__restrict__ A, int64_t rows, int64_t cols,
+                                                   float *__restrict__ row_stats) {
+    __shared__ float red[4];
+    const int64_t r = blockIdx.x;
+    float am = 0.0f;
+    for (int64_t c = threadIdx.x; c < cols; c += 256) am = fmaxf(am, fabsf(to_f32(A[r * cols + c])));
+    am = wave_max(am);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = am;
+    __syncthreads();
+    if (threadIdx.x == 0) row_stats[r] = fmaxf(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])), 1e-8f);
+}
+
+// column absmax: thread per column, 64-row slabs per block in y; non-negative floats order like uints
+template <typename T>
+__global__ __launch_bounds__(256) void k_col_absmax(const T *__restrict__ A, int64_t rows, int64_t cols,
+                                                   uint32_t *__restrict__ col_bits) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    const int64_t r0 = (int64_t)blockIdx.y * 64;
+    const int64_t r1 = r0 + 64 < rows ? r0 + 64 : rows;
+    float am = 0.0f;
+    for (int64_t r = r0; r < r1; r++) am = fmaxf(am, fabsf(to_f32(A[r * cols + c])));
+    atomicMax(col_bits + c, __float_as_uint(am));
+}
+
+__global__ __launch_bounds__(256) void k_clamp_stats(float *__restrict__ s, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) s[i] = fmaxf(s[i], 1e-8f);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_double_quant(const T *__restrict__ A, int64_t rows, int64_t cols,
+                                                     const float *__restrict__ col_stats,
+                                                     const float *__restrict__ row_stats,
+                                                     int8_t *__restrict__ out_col, int8_t *__restrict__ out_row) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * cols) return;
+    const float x = to_f32(A[i]);
+    out_row[i] = quant_i8(x, rscale127(row_stats[i / cols]));  // functional.py:851-854
+    out_col[i] = quant_i8(x, rscale127(col_stats[i % cols]));  // functional.py:858-861
+}
+
+// =====================================================================================
+// host launchers
+// =====================================================================================
+static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <typename T>
+static int launch_quantize_4bit(const void *A, int64_t rows, int64_t cols, int64_t cols_padded, int blocksize,
+                                int qt, const float *absmax_in, uint8_t *packed, float *absmax_out,
+                                hipStream_t st) {
+    const T *a = static_cast<const T *>(A);
+    if (blocksize < 8) {
+        const int64_t nbytes = rows * cols_padded / 2;
+        const unsigned grid = (unsigned)((nbytes + 255) / 256);
+        if (qt == MBNB_NF4)
+            hipLaunchKernelGGL((k_quantize_4bit_tiny<T, MBNB_NF4>), dim3(grid), dim3(256), 0, st, a, rows, cols,
+                               cols_padded, blocksize, absmax_in, packed, absmax_out);
+        else
+            hipLaunchKernelGGL((k_quantize_4bit_tiny<T, MBNB_FP4>), dim3(grid), dim3(256), 0, st, a, rows, cols,
+                               cols_padded, blocksize, absmax_in, packed, absmax_out);
+        return check_launch("quantize_4bit(tiny)");
+    }
+    const bool vec_ok = aligned16(A) && (cols % 8 == 0);
+    const int span = blocksize > 512 ? blocksize : 512;
+    const int64_t waves = rows * ((cols_padded + span - 1) / span);
+    const unsigned grid = (unsigned)((waves + 3) / 4);
+    if (qt == MBNB_NF4)
+        hipLaunchKernelGGL((k_quantize_4bit<T, MBNB_NF4>), dim3(grid), dim3(256), 0, st, a, rows, cols, cols_padded,
+                           blocksize, absmax_in, packed, absmax_out, vec_ok);
+    else
+        hipLaunchKernelGGL((k_quantize_4bit<T, MBNB_FP4>), dim3(grid), dim3(256), 0, st, a, rows, cols, cols_padded,
+                           blocksize, absmax_in, packed, absmax_out, vec_ok);
+    return check_launch("quantize_4bit");
+}
+
+int quantize_4bit_dispatch(const void *A, int dtype, int64_t rows, int64_t cols, int64_t cols_padded,
+                           int blocksize, int qt, const float *absmax_in, uint8_t *packed, float *absmax_out,
+                           hipStream_t st) {
+    switch (dtype) {
+        case MBNB_F16: return launch_quantize_4bit<f16_t>(A, rows, cols, cols_padded, blocksize, qt, absmax_in, packed, absmax_out, st);
+        case MBNB_BF16: return launch_quantize_4bit<bf16_t>(A, rows, cols, cols_padded, blocksize, qt, absmax_in, packed, absmax_out, st);
+        default: return launch_quantize_4bit<float>(A, rows, cols, cols_padded, blocksize, qt, absmax_in, packed, absmax_out, st);
+    }
+}
+
+template <typename T, int QT>
+static int launch_dequantize_4bit(const uint8_t *packed, const AbsmaxView &am, int64_t rows, int64_t cols,
+                                  int64_t cols_padded, int blocksize, void *out, hipStream_t st) {
+    const int64_t groups = rows * ((cols + 7) / 8);
+    const unsigned grid = (unsigned)((groups + 255) / 256);
+    const bool vec_ok = aligned16(out) && (cols % 8 == 0);
+    if (am.i8)
+        hipLaunchKernelGGL((k_dequantize_4bit<T, QT, true>), dim3(grid), dim3(256), 0, st, packed, am, rows, cols,
+                           cols_padded, blocksize, static_cast<T *>(out), vec_ok);
+    else
+        hipLaunchKernelGGL((k_dequantize_4bit<T, QT, false>), dim3(grid), dim3(256), 0, st, packed, am, rows, cols,
+                           cols_padded, blocksize, static_cast<T *>(out), vec_ok);
+    return check_launch("dequantize_4bit");
+}
+
+int dequantize_4bit_dispatch(const uint8_t *packed, const AbsmaxView &am, int64_t rows, int64_t cols,
+                             int64_t cols_padded, int blocksize, int qt, int out_dtype, void *out,
+                             hipStream_t st) {
+#define MBNB_DQ(T)                                                                                              \
+    (qt == MBNB_NF4 ? launch_dequantize_4bit<T, MBNB_NF4>(packed, am, rows, cols, cols_padded, blocksize, out, st) \
+                    : launch_dequantize_4bit<T, MBNB_FP4>(packed, am, rows, cols, cols_padded, blocksize, out, st))
+    switch (out_dtype) {
+        case MBNB_F16: return MBNB_DQ(f16_t);
+        case MBNB_BF16: return MBNB_DQ(bf16_t);
+        default: return MBNB_DQ(float);
+    }
+#undef MBNB_DQ
+}
+
+int quantize_blockwise_dispatch(const void *A, int dtype, int64_t numel, int blocksize, const float *absmax_in,
+                                int8_t *out, float *absmax_out, hipStream_t st) {
+    const unsigned grid = (unsigned)((numel + blocksize - 1) / blocksize);
+    switch (dtype) {
+        case MBNB_F16: hipLaunchKernelGGL(k_quantize_blockwise<f16_t>, dim3(grid), dim3(256), 0, st, static_cast<const f16_t *>(A), numel, blocksize, absmax_in, out, absmax_out); break;
+        case MBNB_BF16: hipLaunchKernelGGL(k_quantize_blockwise<bf16_t>, dim3(grid), dim3(256), 0, st, static_cast<const bf16_t *>(A), numel, blocksize, absmax_in, out, absmax_out); break;
+        default: hipLaunchKernelGGL(k_quantize_blockwise<float>, dim3(grid), dim3(256), 0, st, static_cast<const float *>(A), numel, blocksize, absmax_in, out, absmax_out); break;
+    }
+    return check_launch("quantize_blockwise");
+}
+
+int dequantize_blockwise_dispatch(const int8_t *q, int64_t numel, const float *absmax, int blocksize, int out_dtype,
+                                  void *out, hipStream_t st) {
+    const unsigned grid = (unsigned)((numel + 255) / 256);
+    switch (out_dtype) {
+        case MBNB_F16: hipLaunchKernelGGL(k_dequantize_blockwise<f16_t>, dim3(grid), dim3(256), 0, st, q, numel, absmax, blocksize, static_cast<f16_t *>(out)); break;
+        case MBNB_BF16: hipLaunchKernelGGL(k_dequantize_blockwise<bf16_t>, dim3(grid), dim3(256), 0, st, q, numel, absmax, blocksize, static_cast<bf16_t *>(out)); break;
+        default: hipLaunchKernelGGL(k_dequantize_blockwise<float>, dim3(grid), dim3(256), 0, st, q, numel, absmax, blocksize, static_cast<float *>(out)); break;
+    }
+    return check_launch("dequantize_blockwise");
+}
+
+int quantize_rowwise_dispatch(const void *A, int dtype, int64_t rows, int64_t cols, int8_t *out, float *scales,
+                              hipStream_t st) {
+    const bool vec_ok = aligned16(A) && aligned16(out) && (cols % 8 == 0);
+    const unsigned grid = (unsigned)rows;
+    switch (dtype) {
+        case MBNB_F16: hipLaunchKernelGGL(k_quantize_rowwise<f16_t>, dim3(grid), dim3(256), 0, st, static_cast<const f16_t *>(A), rows, cols, out, scales, vec_ok); break;
+        case MBNB_BF16: hipLaunchKernelGGL(k_quantize_rowwise<bf16_t>, dim3(grid), dim3(256), 0, st, static_cast<const bf16_t *>(A), rows, cols, out, scales, vec_ok); break;
+        default: hipLaunchKernelGGL(k_quantize_rowwise<float>, dim3(grid), dim3(256), 0, st, static_cast<const float *>(A), rows, cols, out, scales, vec_ok); break;
+    }
+    return check_launch("quantize_rowwise");
+}
+
+int dequantize_rowwise_dispatch(const int8_t *q, const float *scales, int64_t rows, int64_t cols, int out_dtype,
+                                void *out, hipStream_t st) {
+    const unsigned grid = (unsigned)((rows * cols + 255) / 256);
+    switch (out_dtype) {
+        case MBNB_F16: hipLaunchKernelGGL(k_dequantize_rowwise<f16_t>, dim3(grid), dim3(256), 0, st, q, scales, rows, cols, static_cast<f16_t *>(out)); break;
+        case MBNB_BF16: hipLaunchKernelGGL(k_dequantize_rowwise<bf16_t>, dim3(grid), dim3(256), 0, st, q, scales, rows, cols, static_cast<bf16_t *>(out)); break;
+        default: hipLaunchKernelGGL(k_dequantize_rowwise<float>, dim3(grid), dim3(256), 0, st, q, scales, rows, cols, static_cast<float *>(out)); break;
+    }
+    return check_launch("dequantize_rowwise");
+}
+
+template <typename T>
+static int launch_double_quant(const void *A, int64_t rows, int64_t cols, int8_t *out_col, int8_t *out_row,
+                               float *col_stats, float *row_stats, int col_given, int row_given, hipStream_t st) {
+    const T *a = static_cast<const T *>(A);
+    if (!row_given) hipLaunchKernelGGL(k_row_absmax<T>, dim3((unsigned)rows), dim3(256), 0, st, a, rows, cols, row_stats);
+    if (!col_given) {
+        hipError_t e = hipMemsetAsync(col_stats, 0, sizeof(float) * cols, st);
+        if (e != hipSuccess) {
+            set_error("double_quant: hipMemsetAsync failed: %s", hipGetErrorString(e));
+            return (int)e;
+        }
+        dim3 grid((unsigned)((cols + 255) / 256), (unsigned)((rows + 63) / 64));
+        hipLaunchKernelGGL(k_col_absmax<T>, grid, dim3(256), 0, st, a, rows, cols, reinterpret_cast<uint32_t *>(col_stats));
+        hipLaunchKernelGGL(k_clamp_stats, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, st, col_stats, cols);
+    }
+    hipLaunchKernelGGL(k_double_quant<T>, dim3((unsigned)((rows * cols + 255) / 256)), dim3(256), 0, st, a, rows, cols,
+                       col_stats, row_stats, out_col, out_row);
+    return check_launch("double_quant");
+}
+
+int double_quant_dispatch(const void *A, int dtype, int64_t rows, int64_t cols, int8_t *out_col, int8_t *out_row,
+                          float *col_stats, float *row_stats, int col_given, int row_given, hipStream_t st) {
+    switch (dtype) {
+        case MBNB_F16: return launch_double_quant<f16_t>(A, rows, cols, out_col, out_row, col_stats, row_stats, col_given, row_given, st);
+        case MBNB_BF16: return launch_double_quant<bf16_t>(A, rows, cols, out_col, out_row, col_stats, row_stats, col_given, row_given, st);
+        default: return launch_double_quant<float>(A, rows, cols, out_col, out_row, col_stats, row_stats, col_given, row_given, st);
+    }
+}
+
+}  // namespace mbnb

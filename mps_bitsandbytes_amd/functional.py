@@ -1,0 +1,612 @@
+"""
+Functional API of the MI355X quantized-linear backend.
+
+Mirrors the reference's ``mps_bitsandbytes/functional.py`` for the quantized-linear hot path
+(same names, argument order, defaults, return types and validation messages) so that user code
+and tests written against the reference read the same here.  Every operation runs as a
+hand-written HIP kernel on gfx950 through the C ABI in ``include/mbnb_hip.h``; tensors must
+live on a ``cuda`` (ROCm) device.  There is no CPU / pure-torch fallback: a missing native
+library or a non-GPU tensor raises.
+
+Host-side work done here is plumbing only: argument validation, shape arithmetic, output
+allocation, dtype casts of activations/bias (reference: functional.py:764-766), stream lookup.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _native
+from ._native import AbsmaxDesc, check, dtype_code, ptr, stream_ptr
+
+# ============================================================================= codebooks
+# reference: functional.py:21-32
+NF4_CODEBOOK = torch.tensor([
+    -1.0, -0.6961928009986877, -0.5250730514526367, -0.39491748809814453,
+    -0.28444138169288635, -0.18477343022823334, -0.09105003625154495, 0.0,
+    0.07958029955625534, 0.16093020141124725, 0.24611230194568634, 0.33791524171829224,
+    0.44070982933044434, 0.5626170039176941, 0.7229568362236023, 1.0
+], dtype=torch.float32)
+
+FP4_CODEBOOK = torch.tensor([
+    0.0, 0.0625, 0.125, 0.25, 0.375, 0.5, 0.75, 1.0,
+    -0.0, -0.0625, -0.125, -0.25, -0.375, -0.5, -0.75, -1.0
+], dtype=torch.float32)
+
+
+def create_normal_map(offset=0.9677083, use_extra_value=True):
+    """NF4 codebook (bitsandbytes compatibility; reference functional.py:35-37)."""
+    return NF4_CODEBOOK.clone()
+
+
+def create_fp4_map(signed=True):
+    """FP4 codebook (bitsandbytes compatibility; reference functional.py:40-42)."""
+    return FP4_CODEBOOK.clone()
+
+
+def _check_device(tensor: Tensor, operation: str = "operation"):
+    """Device gate.  The reference accepts 'mps'/'cpu' (functional.py:76-83); this backend runs
+    on ROCm GPUs only ('cuda' device type) and has no CPU path."""
+    device_type = tensor.device.type
+    if device_type != 'cuda':
+        raise ValueError(
+            f"mps-bitsandbytes-amd {operation} requires tensor on a 'cuda' (ROCm/HIP) device, "
+            f"got '{device_type}'. Move tensor with .to('cuda')"
+        )
+
+
+def _padded(n: int, blocksize: int) -> int:
+    """K_padded rule, reference functional.py:219-221 / :260-262."""
+    p = ((n + blocksize - 1) // blocksize) * blocksize
+    if p % 2 != 0:
+        p += blocksize
+    return p
+
+
+# ============================================================================= QuantState
+@dataclass
+class QuantState:
+    """
+    Quantization state for dequantization (reference: functional.py:90-156; field-for-field
+    identical, including ``as_dict`` keys — this is the checkpoint wire format).
+    """
+    absmax: Tensor
+    shape: torch.Size
+    code: Optional[Tensor] = None
+    blocksize: int = 64
+    quant_type: str = "nf4"
+    dtype: torch.dtype = torch.float16
+    offset: Optional[Tensor] = None
+    state2: Optional['QuantState'] = None
+
+    def __post_init__(self):
+        if self.code is None:
+            self.code = NF4_CODEBOOK if self.quant_type == "nf4" else FP4_CODEBOOK
+
+    def to(self, device):
+        """Move state to device (in place, recursive)."""
+        self.absmax = self.absmax.to(device)
+        if self.code is not None:
+            self.code = self.code.to(device)
+        if self.offset is not None:
+            self.offset = self.offset.to(device)
+        if self.state2 is not None:
+            self.state2 = self.state2.to(device)
+        return self
+
+    def as_dict(self, packed=False):
+        return {
+            'absmax': self.absmax,
+            'shape': self.shape,
+            'blocksize': self.blocksize,
+            'quant_type': self.quant_type,
+            'dtype': self.dtype,
+            'state2': self.state2.as_dict() if self.state2 else None,
+        }
+
+    @classmethod
+    def from_dict(cls, state_dict, device='cpu'):
+        state2 = None
+        if state_dict.get('state2') is not None:
+            state2 = cls.from_dict(state_dict['state2'], device)
+        return cls(
+            absmax=state_dict['absmax'].to(device),
+            shape=state_dict['shape'],
+            blocksize=state_dict.get('blocksize', 64),
+            quant_type=state_dict.get('quant_type', 'nf4'),
+            dtype=state_dict.get('dtype', torch.float16),
+            state2=state2,
+        )
+
+
+def _absmax_desc(absmax: Tensor, state2: Optional[QuantState], keep: list) -> AbsmaxDesc:
+    """Build the C descriptor of an absmax tensor.  One level of int8 double-quant
+    (QuantState.state2 as produced by quantize_4bit, functional.py:288-292) is decoded inside the
+    consuming kernel; anything else is first brought to plain f32 by dequantize_blockwise.
+    `keep` collects tensors that must stay alive until the launch has been enqueued."""
+    if state2 is not None:
+        if (absmax.dtype == torch.int8 and state2.state2 is None and state2.dtype == torch.float32
+                and state2.absmax.dtype == torch.float32):
+            q = absmax.contiguous()
+            a2 = state2.absmax.contiguous()
+            keep += [q, a2]
+            return AbsmaxDesc(None, q.data_ptr(), a2.data_ptr(), int(state2.blocksize))
+        absmax = dequantize_blockwise(absmax, state2)
+    a = absmax.to(torch.float32).contiguous()
+    keep.append(a)
+    return AbsmaxDesc(a.data_ptr(), None, None, 0)
+
+
+# ============================================================================= 4-bit
+def quantize_4bit(
+    A: Tensor,
+    absmax: Optional[Tensor] = None,
+    out: Optional[Tensor] = None,
+    blocksize: int = 64,
+    compress_statistics: bool = False,
+    quant_type: str = "nf4",
+    quant_storage: torch.dtype = torch.uint8,
+) -> Tuple[Tensor, QuantState]:
+    """
+    Quantize tensor to 4-bit NF4 or FP4 (reference: functional.py:163-303, bit-exact).
+
+    2-D tensors [N, K] are quantized row-wise (each row padded to a multiple of `blocksize`);
+    other shapes over the flattened tensor.  Returns (packed uint8 flat tensor, QuantState).
+    """
+    if quant_type not in ("nf4", "fp4"):
+        raise ValueError(f"quant_type must be 'nf4' or 'fp4', got {quant_type}")
+    _check_device(A, "quantize_4bit")
+    if blocksize <= 0:
+        raise ValueError(f"blocksize must be positive, got {blocksize}")
+    if blocksize > 65536:
+        raise ValueError(f"blocksize too large ({blocksize}), max is 65536")
+    if (blocksize & (blocksize - 1)) != 0:
+        raise ValueError(f"blocksize must be a power of 2, got {blocksize}")
+    max_safe_numel = 2**31 - 1
+    if A.numel() > max_safe_numel:
+        raise ValueError(f"Tensor too large ({A.numel()} elements), max is {max_safe_numel}")
+
+    orig_shape = A.shape
+    orig_dtype = A.dtype
+    code = dtype_code(orig_dtype, "quantize_4bit")
+    A = A.contiguous()
+    if A.dim() == 2:
+        rows, cols = A.shape
+    else:
+        rows, cols = 1, A.numel()
+    cols_padded = _padded(cols, blocksize)
+    nbytes = rows * cols_padded // 2
+    nblocks = rows * cols_padded // blocksize
+
+    user_out = out
+    if (out is not None and out.dtype == torch.uint8 and out.is_contiguous() and out.numel() == nbytes
+            and out.device == A.device):
+        packed = out.view(-1)
+    else:
+        packed = torch.empty(nbytes, dtype=torch.uint8, device=A.device)
+    if blocksize == 1:
+        packed.zero_()
+    absmax_in = None
+    if absmax is not None:
+        absmax_in = absmax.to(device=A.device, dtype=torch.float32).contiguous().view(-1)
+        if absmax_in.numel() != nblocks:
+            raise ValueError(f"absmax has {absmax_in.numel()} elements, expected {nblocks}")
+    absmax_out = torch.empty(nblocks, dtype=torch.float32, device=A.device)
+
+    with torch.cuda.device(A.device):
+        check(_native.lib().mbnb_quantize_4bit(
+            ptr(A), code, rows, cols, cols_padded, int(blocksize), _native.QUANT_CODE[quant_type],
+            ptr(absmax_in), ptr(packed), ptr(absmax_out), stream_ptr(A.device)), "quantize_4bit")
+
+    if user_out is not None and packed.data_ptr() != user_out.data_ptr():
+        user_out.view(-1)[:] = packed.to(user_out.dtype)  # reference: out[:] = ... (functional.py:251)
+        packed = user_out.flatten()
+    elif quant_storage != torch.uint8:
+        packed = packed.to(quant_storage)
+
+    absmax_t = absmax_out
+    state2 = None
+    if compress_statistics:
+        absmax_t, state2 = quantize_blockwise(absmax_out, blocksize=256)
+
+    quant_state = QuantState(
+        absmax=absmax_t,
+        shape=orig_shape,
+        blocksize=blocksize,
+        quant_type=quant_type,
+        dtype=orig_dtype,
+        state2=state2,
+    )
+    return packed, quant_state
+
+
+def dequantize_4bit(
+    A: Tensor,
+    quant_state: Optional[QuantState] = None,
+    absmax: Optional[Tensor] = None,
+    out: Optional[Tensor] = None,
+    blocksize: int = 64,
+    quant_type: str = "nf4",
+) -> Tensor:
+    """Dequantize a 4-bit tensor (reference: functional.py:306-416, bit-exact)."""
+    _check_device(A, "dequantize_4bit")
+    state2 = None
+    if quant_state is not None:
+        absmax = quant_state.absmax
+        blocksize = quant_state.blocksize
+        quant_type = quant_state.quant_type
+        shape = quant_state.shape
+        dtype = quant_state.dtype
+        state2 = quant_state.state2
+    else:
+        if absmax is None:
+            raise ValueError("Either quant_state or absmax must be provided")
+        shape = None
+        dtype = torch.float16
+    if quant_type not in ("nf4", "fp4"):
+        raise ValueError(f"quant_type must be 'nf4' or 'fp4', got {quant_type}")
+
+    A = A.contiguous()
+    if A.dtype != torch.uint8:
+        A = A.to(torch.uint8)
+    if shape is not None and len(shape) == 2:
+        rows, cols = int(shape[0]), int(shape[1])
+        cols_padded = _padded(cols, blocksize)
+        out_shape = (rows, cols)
+    else:
+        # flat layout: the number of blocks is what absmax says (functional.py:399-401)
+        rows = 1
+        cols_padded = absmax.numel() * blocksize
+        if shape is not None:
+            cols = int(torch.Size(shape).numel())
+            out_shape = tuple(shape)
+        elif out is not None:
+            cols = out.numel()
+            out_shape = tuple(out.shape)
+        else:
+            cols = cols_padded
+            out_shape = (cols,)
+    if A.numel() * 2 < rows * cols_padded or cols > cols_padded:
+        raise ValueError(
+            f"packed tensor has {A.numel()} bytes but absmax/shape describe {rows * cols_padded} 4-bit values")
+
+    keep: list = []
+    desc = _absmax_desc(absmax.to(A.device), state2, keep)
+    direct = (out is not None and out.dtype == dtype and out.is_contiguous() and out.numel() == rows * cols
+              and out.device == A.device)
+    result = out if direct else torch.empty(out_shape, dtype=dtype, device=A.device)
+    with torch.cuda.device(A.device):
+        check(_native.lib().mbnb_dequantize_4bit(
+            ptr(A), ctypes.byref(desc), rows, cols, cols_padded, int(blocksize), _native.QUANT_CODE[quant_type],
+            dtype_code(dtype, "dequantize_4bit"), ptr(result), stream_ptr(A.device)), "dequantize_4bit")
+    if out is not None and not direct:
+        out[:] = result.view(out.shape).to(out.dtype)
+        return out
+    return result
+
+
+def quantize_nf4(A: Tensor, absmax: Optional[Tensor] = None, out: Optional[Tensor] = None, blocksize: int = 64,
+                 compress_statistics: bool = False, quant_storage: torch.dtype = torch.uint8):
+    """Alias for quantize_4bit with quant_type='nf4' (reference functional.py:419-428)."""
+    return quantize_4bit(A, absmax, out, blocksize, compress_statistics, "nf4", quant_storage)
+
+
+def dequantize_nf4(A: Tensor, quant_state: Optional[QuantState] = None, absmax: Optional[Tensor] = None,
+                   out: Optional[Tensor] = None, blocksize: int = 64) -> Tensor:
+    """Alias for dequantize_4bit with quant_type='nf4' (reference functional.py:431-439)."""
+    return dequantize_4bit(A, quant_state, absmax, out, blocksize, "nf4")
+
+
+def quantize_fp4(A: Tensor, absmax: Optional[Tensor] = None, out: Optional[Tensor] = None, blocksize: int = 64,
+                 compress_statistics: bool = False, quant_storage: torch.dtype = torch.uint8):
+    """Alias for quantize_4bit with quant_type='fp4' (reference functional.py:442-451)."""
+    return quantize_4bit(A, absmax, out, blocksize, compress_statistics, "fp4", quant_storage)
+
+
+def dequantize_fp4(A: Tensor, quant_state: Optional[QuantState] = None, absmax: Optional[Tensor] = None,
+                   out: Optional[Tensor] = None, blocksize: int = 64) -> Tensor:
+    """Alias for dequantize_4bit with quant_type='fp4' (reference functional.py:454-462)."""
+    return dequantize_4bit(A, quant_state, absmax, out, blocksize, "fp4")
+
+
+# ============================================================================= blockwise int8
+def quantize_blockwise(
+    A: Tensor,
+    code: Optional[Tensor] = None,
+    absmax: Optional[Tensor] = None,
+    out: Optional[Tensor] = None,
+    blocksize: int = 4096,
+    nested: bool = False,
+) -> Tuple[Tensor, QuantState]:
+    """INT8 blockwise absmax quantization (reference: functional.py:469-539, bit-exact)."""
+    _check_device(A, "quantize_blockwise")
+    if blocksize <= 0:
+        raise ValueError(f"blocksize must be positive, got {blocksize}")
+    if blocksize > 65536:
+        raise ValueError(f"blocksize too large ({blocksize}), max is 65536")
+    orig_shape = A.shape
+    orig_dtype = A.dtype
+    dcode = dtype_code(orig_dtype, "quantize_blockwise")
+    A = A.contiguous()
+    numel = A.numel()
+    nblocks = (numel + blocksize - 1) // blocksize
+    absmax_in = None
+    if absmax is not None:
+        absmax_in = absmax.to(device=A.device, dtype=torch.float32).contiguous().view(-1)
+    q = torch.empty(numel, dtype=torch.int8, device=A.device)
+    absmax_out = torch.empty(nblocks, dtype=torch.float32, device=A.device)
+    with torch.cuda.device(A.device):
+        check(_native.lib().mbnb_quantize_blockwise(
+            ptr(A), dcode, numel, int(blocksize), ptr(absmax_in), ptr(q), ptr(absmax_out),
+            stream_ptr(A.device)), "quantize_blockwise")
+    if out is not None:
+        out.view(-1)[:numel] = q  # reference writes the blocked result into `out` (functional.py:522)
+    q = q.view(orig_shape)
+
+    absmax_t = absmax_out
+    state2 = None
+    if nested:
+        absmax_t, state2 = quantize_blockwise(absmax_out, blocksize=256)
+    quant_state = QuantState(
+        absmax=absmax_t,
+        shape=orig_shape,
+        blocksize=blocksize,
+        quant_type="int8",
+        dtype=orig_dtype,
+        state2=state2,
+    )
+    return q, quant_state
+
+
+def dequantize_blockwise(
+    A: Tensor,
+    quant_state: Optional[QuantState] = None,
+    absmax: Optional[Tensor] = None,
+    code: Optional[Tensor] = None,
+    out: Optional[Tensor] = None,
+    blocksize: int = 4096,
+    nested: bool = False,
+) -> Tensor:
+    """Dequantize blockwise INT8 (reference: functional.py:542-600, bit-exact)."""
+    _check_device(A, "dequantize_blockwise")
+    if quant_state is not None:
+        absmax = quant_state.absmax
+        blocksize = quant_state.blocksize
+        shape = quant_state.shape
+        dtype = quant_state.dtype
+        if quant_state.state2 is not None:
+            absmax = dequantize_blockwise(absmax, quant_state.state2)
+    else:
+        if absmax is None:
+            raise ValueError("Either quant_state or absmax must be provided")
+        shape = A.shape
+        dtype = torch.float16
+    q = A.contiguous()
+    if q.dtype != torch.int8:
+        q = q.to(torch.int8)
+    numel = q.numel()
+    am = absmax.to(device=A.device, dtype=torch.float32).contiguous()
+    result = torch.empty(numel, dtype=dtype, device=A.device)
+    with torch.cuda.device(A.device):
+        check(_native.lib().mbnb_dequantize_blockwise(
+            ptr(q), numel, ptr(am), int(blocksize), dtype_code(dtype, "dequantize_blockwise"), ptr(result),
+            stream_ptr(A.device)), "dequantize_blockwise")
+    result = result.view(shape)
+    if out is not None:
+        out[:] = result
+        return out
+    return result
+
+
+# ============================================================================= rowwise int8
+def quantize_rowwise(tensor: Tensor) -> Tuple[Tensor, Tensor]:
+    """Row-wise absmax INT8 quantization (reference: functional.py:607-625, bit-exact).
+    Returns (int8 tensor of the same shape, scales f32 [rows]); scales hold the absmax itself."""
+    _check_device(tensor, "quantize_rowwise")
+    orig_shape = tensor.shape
+    t = tensor.contiguous()
+    cols = t.shape[-1]
+    rows = t.numel() // cols if cols else 0
+    q = torch.empty(t.shape, dtype=torch.int8, device=t.device)
+    scales = torch.empty(rows, dtype=torch.float32, device=t.device)
+    with torch.cuda.device(t.device):
+        check(_native.lib().mbnb_quantize_rowwise(
+            ptr(t), dtype_code(t.dtype, "quantize_rowwise"), rows, cols, ptr(q), ptr(scales),
+            stream_ptr(t.device)), "quantize_rowwise")
+    return q.view(orig_shape), scales
+
+
+def dequantize_rowwise(quantized: Tensor, scales: Tensor, dtype: torch.dtype = torch.float16) -> Tensor:
+    """Dequantize row-wise INT8 (reference: functional.py:628-636, bit-exact)."""
+    _check_device(quantized, "dequantize_rowwise")
+    orig_shape = quantized.shape
+    q = quantized.contiguous()
+    cols = q.shape[-1]
+    rows = q.numel() // cols if cols else 0
+    s = scales.to(device=q.device, dtype=torch.float32).contiguous().view(-1)
+    if s.numel() != rows:
+        raise ValueError(f"scales has {s.numel()} elements, expected {rows}")
+    out = torch.empty(q.shape, dtype=dtype, device=q.device)
+    with torch.cuda.device(q.device):
+        check(_native.lib().mbnb_dequantize_rowwise(
+            ptr(q), ptr(s), rows, cols, dtype_code(dtype, "dequantize_rowwise"), ptr(out),
+            stream_ptr(q.device)), "dequantize_rowwise")
+    return out.view(orig_shape)
+
+
+# ============================================================================= matmuls
+def matmul_4bit(
+    A: Tensor,
+    B: Tensor,
+    quant_state: QuantState,
+    bias: Optional[Tensor] = None,
+    compute_dtype: Optional[torch.dtype] = None,
+) -> Tensor:
+    """
+    Matrix multiplication with 4-bit quantized weights: ``A[..., K] @ dequant(B)[N, K]^T + bias``.
+
+    Signature of the reference (functional.py:680-773).  One fused HIP kernel for every M (the
+    reference fuses only on MPS and only for M <= 512): the decoded weight is rounded to
+    ``quant_state.dtype`` exactly as ``dequantize_4bit`` would, the contraction runs in that
+    dtype with f32 accumulation, and the result is cast to ``compute_dtype`` (default
+    ``A.dtype``) — the numerics of the reference's CPU branch (functional.py:756-773).
+    """
+    if compute_dtype is None:
+        compute_dtype = A.dtype
+    _check_device(A, "matmul_4bit")
+    _check_device(B, "matmul_4bit")
+    if len(quant_state.shape) != 2:
+        raise ValueError(f"matmul_4bit needs a 2-D quantized weight, got shape {tuple(quant_state.shape)}")
+    N, K = int(quant_state.shape[0]), int(quant_state.shape[1])
+    if A.shape[-1] != K:
+        raise RuntimeError(
+            f"mat1 and mat2 shapes cannot be multiplied ({A.numel() // max(A.shape[-1], 1)}x{A.shape[-1]} and {K}x{N})")
+    blocksize = quant_state.blocksize
+    K_weight = _padded(K, blocksize)
+    w_dtype = quant_state.dtype
+    w_code = dtype_code(w_dtype, "matmul_4bit")
+
+    orig_shape = A.shape
+    A2 = A.reshape(-1, K).to(w_dtype).contiguous()   # reference: A.to(weight.dtype), functional.py:764
+    M = A2.shape[0]
+    bias_w = None
+    if bias is not None:
+        bias_w = bias.to(device=A.device, dtype=w_dtype).contiguous()  # functional.py:765-766
+    packed = B.contiguous()
+    if packed.dtype != torch.uint8:
+        packed = packed.to(torch.uint8)
+    if packed.numel() * 2 < N * K_weight:
+        raise ValueError(f"packed weight has {packed.numel()} bytes, expected {N * K_weight // 2}")
+
+    out_dtype = compute_dtype if compute_dtype in _native.DTYPE_CODE else w_dtype
+    out = torch.empty(M, N, dtype=out_dtype, device=A.device)
+    keep: list = []
+    desc = _absmax_desc(quant_state.absmax.to(A.device), quant_state.state2, keep)
+    with torch.cuda.device(A.device):
+        check(_native.lib().mbnb_matmul_4bit(
+            ptr(A2), M, K, ptr(packed), ctypes.byref(desc), N, K_weight, int(blocksize),
+            _native.QUANT_CODE[quant_state.quant_type], w_code, ptr(bias_w), _native.DTYPE_CODE[out_dtype],
+            ptr(out), stream_ptr(A.device)), "matmul_4bit")
+    if out_dtype != compute_dtype:
+        out = out.to(compute_dtype)
+    return out.reshape(*orig_shape[:-1], N)
+
+
+def matmul_nf4(input: Tensor, weight_packed: Tensor, weight_state: QuantState,
+               bias: Optional[Tensor] = None) -> Tensor:
+    """Matrix multiplication with NF4-quantized weights (reference functional.py:776-779)."""
+    return matmul_4bit(input, weight_packed, weight_state, bias)
+
+
+def matmul_fp4(input: Tensor, weight_packed: Tensor, weight_state: QuantState,
+               bias: Optional[Tensor] = None) -> Tensor:
+    """Matrix multiplication with FP4-quantized weights (reference functional.py:782-785)."""
+    return matmul_4bit(input, weight_packed, weight_state, bias)
+
+
+def matmul_int8(A: Tensor, B: Tensor, A_scales: Tensor, B_scales: Tensor,
+                dtype: torch.dtype = torch.float16) -> Tensor:
+    """
+    INT8 matmul with fused dequantization (reference: functional.py:788-793).
+
+    A int8 [M, K] with one scale per row; B int8 [K, N] with one scale per column.  Computed as
+    ``int32(A·B) * (sA[m]/127) * (sB[n]/127)`` on the int8 MFMA (what the reference's Metal kernel
+    mm:155-196 computes; equal to the reference CPU formulation within 4e-4 rel-err).
+    """
+    _check_device(A, "matmul_int8")
+    _check_device(B, "matmul_int8")
+    if A.dim() != 2 or B.dim() != 2 or A.shape[1] != B.shape[0]:
+        raise RuntimeError(f"matmul_int8: shapes {tuple(A.shape)} and {tuple(B.shape)} cannot be multiplied")
+    A = A.contiguous()
+    B = B.contiguous()
+    if A.dtype != torch.int8 or B.dtype != torch.int8:
+        raise TypeError("matmul_int8: A and B must be int8")
+    M, K = A.shape
+    N = B.shape[1]
+    sa = A_scales.to(device=A.device, dtype=torch.float32).contiguous().view(-1)
+    sb = B_scales.to(device=A.device, dtype=torch.float32).contiguous().view(-1)
+    if sa.numel() != M or sb.numel() != N:
+        raise ValueError(f"matmul_int8: need {M} A_scales and {N} B_scales, got {sa.numel()} and {sb.numel()}")
+    out_dtype = dtype if dtype in _native.DTYPE_CODE else torch.float32
+    out = torch.empty(M, N, dtype=out_dtype, device=A.device)
+    workspace = torch.empty(N * K, dtype=torch.int8, device=A.device)
+    with torch.cuda.device(A.device):
+        check(_native.lib().mbnb_matmul_int8(
+            ptr(A), ptr(B), ptr(sa), ptr(sb), M, N, K, _native.DTYPE_CODE[out_dtype], ptr(out), ptr(workspace),
+            stream_ptr(A.device)), "matmul_int8")
+    return out if out_dtype == dtype else out.to(dtype)
+
+
+def linear_int8(input: Tensor, weight_int8: Tensor, weight_scales: Tensor, bias: Optional[Tensor] = None,
+                dtype: Optional[torch.dtype] = None) -> Tensor:
+    """
+    ``input[..., K] @ dequantize_rowwise(weight_int8[N, K], weight_scales, dtype)^T + bias`` in one
+    kernel — the forward of Linear8bit (reference: nn/linear8bit.py:70-102; native binding
+    `_C.linear_int8`, mm:1836-1886).
+    """
+    _check_device(input, "linear_int8")
+    _check_device(weight_int8, "linear_int8")
+    if dtype is None:
+        dtype = input.dtype
+    dcode = dtype_code(dtype, "linear_int8")
+    N, K = weight_int8.shape
+    if input.shape[-1] != K:
+        raise RuntimeError(f"linear_int8: input width {input.shape[-1]} does not match weight {tuple(weight_int8.shape)}")
+    x = input.reshape(-1, K).to(dtype).contiguous()
+    M = x.shape[0]
+    w = weight_int8.contiguous()
+    s = weight_scales.to(device=x.device, dtype=torch.float32).contiguous()
+    b = None if bias is None else bias.to(device=x.device, dtype=dtype).contiguous()
+    out = torch.empty(M, N, dtype=dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        check(_native.lib().mbnb_linear_int8(ptr(x), dcode, M, K, ptr(w), ptr(s), N, ptr(b), ptr(out),
+                                             stream_ptr(x.device)), "linear_int8")
+    return out.reshape(*input.shape[:-1], N)
+
+
+# ============================================================================= double quant (LLM.int8 stats)
+def double_quant(
+    A: Tensor,
+    col_stats: Optional[Tensor] = None,
+    row_stats: Optional[Tensor] = None,
+    out_col: Optional[Tensor] = None,
+    out_row: Optional[Tensor] = None,
+    threshold: float = 0.0,
+) -> Tuple[Tensor, Tensor, Tensor, Tensor, Optional[Tensor]]:
+    """
+    Row- and column-wise INT8 quantization with their absmax statistics
+    (reference: functional.py:814-863, bit-exact).  Returns
+    (col_quantized, row_quantized, col_stats, row_stats, None); `threshold` is ignored as in the
+    reference, and caller-supplied out_col / out_row are returned untouched as there.
+    """
+    if A.dim() != 2:
+        raise ValueError("Input must be 2D")
+    _check_device(A, "double_quant")
+    A = A.contiguous()
+    rows, cols = A.shape
+    dcode = dtype_code(A.dtype, "double_quant")
+    cs = (torch.empty(cols, dtype=torch.float32, device=A.device) if col_stats is None
+          else col_stats.to(device=A.device, dtype=torch.float32).contiguous().clone())
+    rs = (torch.empty(rows, dtype=torch.float32, device=A.device) if row_stats is None
+          else row_stats.to(device=A.device, dtype=torch.float32).contiguous().clone())
+    oc = torch.empty(A.shape, dtype=torch.int8, device=A.device)
+    orow = torch.empty(A.shape, dtype=torch.int8, device=A.device)
+    with torch.cuda.device(A.device):
+        check(_native.lib().mbnb_double_quant(
+            ptr(A), dcode, rows, cols, ptr(oc), ptr(orow), ptr(cs), ptr(rs), int(col_stats is not None),
+            int(row_stats is not None), stream_ptr(A.device)), "double_quant")
+    return (oc if out_col is None else out_col, orow if out_row is None else out_row,
+            cs if col_stats is None else col_stats, rs if row_stats is None else row_stats, None)
+
+
+def dequant_absmax(absmax_quant: Tensor, absmax_scales, blocksize: int = 256) -> Tensor:
+    """Dequantize double-quantized absmax values (reference: functional.py:866-889).
+    Only the live form (a QuantState in `absmax_scales`) is supported; the legacy per-row
+    uint8 form is unreachable from Linear4bit."""
+    if isinstance(absmax_scales, QuantState):
+        return dequantize_blockwise(absmax_quant, absmax_scales)
+    raise NotImplementedError("dequant_absmax: only the QuantState form is supported on this backend")

@@ -1,0 +1,53 @@
+"""
+Batch-row sharding of a quantized linear across the GPUs of one node.
+
+`out[m, :]` depends only on `A[m, :]` and the read-only weight, so the path shards by rows with
+no data-path collective: weights (packed + absmax [+ state2] + bias) are replicated, each rank
+computes its contiguous block of rows.  The one exchange step the north-star names is an
+all-gather of the output shards (RCCL over xGMI on GPUs, `backend="nccl"`; gloo on CPU in the
+tests).  One process per GPU; this module holds no kernel code.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def row_shard(M_global: int, rank: int, world_size: int) -> Tuple[int, int]:
+    """[start, stop) of the rows owned by `rank`: contiguous blocks, the first
+    `M_global % world_size` ranks take one extra row."""
+    if world_size <= 0 or not (0 <= rank < world_size):
+        raise ValueError(f"bad rank/world_size {rank}/{world_size}")
+    base, extra = divmod(M_global, world_size)
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+def sharded_linear(local_rows: torch.Tensor, forward: Callable[[torch.Tensor], torch.Tensor], M_global: int,
+                   gather: bool = True, group: Optional[dist.ProcessGroup] = None,
+                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Apply `forward` (e.g. a Linear4bit) to this rank's rows and, if `gather`, all-gather the
+    [M_global, N] result on every rank.  Equal shards use one all_gather_into_tensor (a single
+    RCCL call on GPUs); ragged shards are padded to the largest shard for the same single call."""
+    y_local = forward(local_rows)
+    if not gather or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return y_local
+    world = dist.get_world_size(group)
+    N = y_local.shape[-1]
+    if out is None:
+        out = torch.empty(M_global, N, dtype=y_local.dtype, device=y_local.device)
+    if M_global % world == 0:
+        dist.all_gather_into_tensor(out, y_local.contiguous(), group=group)
+    else:
+        # ragged: pad every shard to the largest one, gather once, then drop the pad rows
+        max_rows = (M_global + world - 1) // world
+        padded = torch.zeros(max_rows, N, dtype=y_local.dtype, device=y_local.device)
+        padded[: y_local.shape[0]] = y_local
+        staged = torch.empty(world * max_rows, N, dtype=y_local.dtype, device=y_local.device)
+        dist.all_gather_into_tensor(staged, padded, group=group)
+        for r in range(world):
+            s, e = row_shard(M_global, r, world)
+            out[s:e] = staged[r * max_rows: r * max_rows + (e - s)]
+    return out

@@ -1,0 +1,124 @@
+"""Host-side logic of the Python mirror (no GPU): QuantState wire format, validation messages
+(the reference's tests match them by regex, tests/test_fp4_fp8_double.py:414-460), shape
+arithmetic, module construction and state-dict keys — pinned to what the reference produced
+(tests/golden/manifest.json 'api')."""
+import pytest
+import torch
+
+import mps_bitsandbytes_amd as bnb
+from mps_bitsandbytes_amd import functional as F
+from mps_bitsandbytes_amd.functional import QuantState
+from mps_bitsandbytes_amd.sharding import row_shard
+
+
+def test_codebooks_match_reference_tables():
+    assert F.NF4_CODEBOOK.dtype == torch.float32 and F.NF4_CODEBOOK.numel() == 16
+    assert F.NF4_CODEBOOK[7].item() == 0.0 and F.NF4_CODEBOOK[0].item() == -1.0 and F.NF4_CODEBOOK[15].item() == 1.0
+    assert torch.equal(torch.sort(F.NF4_CODEBOOK).values, F.NF4_CODEBOOK)
+    assert F.FP4_CODEBOOK.tolist()[:8] == [0.0, 0.0625, 0.125, 0.25, 0.375, 0.5, 0.75, 1.0]
+    assert torch.equal(F.FP4_CODEBOOK[8:], -F.FP4_CODEBOOK[:8])
+    assert torch.equal(bnb.create_normal_map(), F.NF4_CODEBOOK) and torch.equal(bnb.create_fp4_map(), F.FP4_CODEBOOK)
+
+
+def test_padding_rule():
+    assert F._padded(4096, 64) == 4096
+    assert F._padded(70, 64) == 128
+    assert F._padded(13, 64) == 64
+    assert F._padded(3, 1) == 4       # odd -> + blocksize (functional.py:220-221)
+    assert F._padded(1, 1) == 2
+
+
+def test_quantstate_dict_roundtrip(golden):
+    st2 = QuantState(absmax=torch.ones(3), shape=torch.Size([700]), blocksize=256, quant_type="int8", dtype=torch.float32)
+    st = QuantState(absmax=torch.zeros(700, dtype=torch.int8), shape=torch.Size([10, 70]), blocksize=64,
+                    quant_type="fp4", dtype=torch.bfloat16, state2=st2)
+    assert torch.equal(st.code, F.FP4_CODEBOOK)
+    d = st.as_dict()
+    assert sorted(d.keys()) == golden.manifest["api"]["quant_state_dict_keys"]
+    assert sorted(d["state2"].keys()) == golden.manifest["api"]["state2_dict_keys"]
+    back = QuantState.from_dict(d)
+    assert back.blocksize == 64 and back.quant_type == "fp4" and back.dtype == torch.bfloat16
+    assert back.state2.blocksize == 256 and torch.equal(back.state2.absmax, st2.absmax)
+    assert QuantState(absmax=torch.ones(1), shape=torch.Size([1])).quant_type == "nf4"
+
+
+def test_validation_messages_match_reference(golden):
+    msgs = golden.manifest["api"]["error_messages"]
+    x = torch.zeros(4, 64)
+    for name, kw in (("neg", dict(blocksize=-1)), ("zero", dict(blocksize=0)), ("large", dict(blocksize=131072)),
+                     ("pow2", dict(blocksize=48)), ("qtype", dict(quant_type="int4"))):
+        with pytest.raises(ValueError) as e:
+            # quant_type is validated before the device, blocksize after it (reference order):
+            # use a meta 'cuda' check bypass by validating on the message only for quant_type
+            if name == "qtype":
+                bnb.quantize_4bit(x, **kw)
+            else:
+                _validate_blocksize_like_reference(**kw)
+        assert str(e.value) == msgs[name]
+
+
+def _validate_blocksize_like_reference(blocksize):
+    """quantize_4bit's blocksize checks sit behind the device gate; exercise them through a
+    tensor whose device type reads 'cuda' without needing a GPU."""
+    class FakeCuda(torch.Tensor):
+        @property
+        def device(self):
+            return torch.device("cuda", 0)
+    t = torch.zeros(4, 64).as_subclass(FakeCuda)
+    return bnb.quantize_4bit(t, blocksize=blocksize)
+
+
+def test_blockwise_validation_message(golden):
+    class FakeCuda(torch.Tensor):
+        @property
+        def device(self):
+            return torch.device("cuda", 0)
+    with pytest.raises(ValueError) as e:
+        bnb.quantize_blockwise(torch.zeros(8).as_subclass(FakeCuda), blocksize=0)
+    assert str(e.value) == golden.manifest["api"]["error_messages"]["blockwise_zero"]
+
+
+def test_linear4bit_construction_and_state_dict_keys(golden):
+    api = golden.manifest["api"]
+    l4 = bnb.Linear4bit(70, 5)
+    assert l4.weight.dtype == torch.uint8 and l4.weight.numel() == api["linear4bit_ctor_weight_numel"]
+    assert l4.bias.dtype == torch.float16 and l4.weight_quant_state is None and l4.quant_state is None
+    with pytest.raises(RuntimeError, match="Weight not quantized"):
+        l4(torch.zeros(1, 70))
+    with pytest.raises(ValueError, match="quant_type must be"):
+        bnb.Linear4bit(8, 8, quant_type="int4")
+    # a checkpoint produced elsewhere loads on CPU without running any kernel
+    st2 = QuantState(absmax=torch.ones(1), shape=torch.Size([10]), blocksize=256, quant_type="int8", dtype=torch.float32)
+    st = QuantState(absmax=torch.zeros(10, dtype=torch.int8), shape=torch.Size([5, 70]), blocksize=64, state2=st2)
+    l4.weight = torch.zeros(api["linear4bit_weight_numel"], dtype=torch.uint8)
+    l4.weight_quant_state = st
+    sd = l4.state_dict()
+    assert sorted(sd.keys()) == api["linear4bit_state_dict_keys"]
+    fresh = bnb.Linear4bit(70, 5, blocksize=128, quant_type="fp4")
+    with pytest.warns(UserWarning, match="mismatch"):
+        fresh.load_state_dict(sd)
+    assert fresh.blocksize == 64 and fresh.quant_type == "nf4"
+    assert fresh.weight.numel() == api["linear4bit_weight_numel"]
+    assert fresh.weight_quant_state.state2.blocksize == 256
+    assert "quant_type=nf4" in repr(fresh)
+    assert fresh.device.type == "cpu"
+
+
+def test_linear8bit_construction(golden):
+    l8 = bnb.Linear8bit(32, 16, bias=True, compute_dtype=torch.bfloat16)
+    assert sorted(l8.state_dict().keys()) == golden.manifest["api"]["linear8bit_state_dict_keys"]
+    assert l8.weight_int8.shape == (16, 32) and l8.weight_int8.dtype == torch.int8
+    assert l8.weight_scales.dtype == torch.float32 and l8.bias.dtype == torch.bfloat16
+    l8.clear_cache()
+    assert l8._weight_cache is None and l8.device.type == "cpu"
+
+
+def test_row_shard_partitions_exactly():
+    for M, w in ((32768, 8), (4096, 1), (10, 4), (3, 8), (0, 2)):
+        spans = [row_shard(M, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == M
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+        sizes = [e - s for s, e in spans]
+        assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        row_shard(8, 2, 2)

@@ -1,0 +1,75 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol
+include/mbnb_hip.h declares (no compute calls — there is no GPU here), and argument errors are
+reported through the status / last-error convention without touching a device."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from mps_bitsandbytes_amd import _native
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "mbnb_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mbnb_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = _native.lib()
+    names = _declared_symbols()
+    assert len(names) >= 13
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/mbnb_hip.h but not exported"
+    assert sorted(_native.EXPORTED_SYMBOLS) == names, "python binding and header disagree"
+    assert lib.mbnb_abi_version() == 1
+
+
+def test_argument_errors_use_status_and_last_error():
+    lib = _native.lib()
+    rc = lib.mbnb_quantize_4bit(None, 0, 4, 64, 64, 48, 0, None, None, None, None)
+    assert rc == -1 and b"power of 2" in lib.mbnb_last_error()
+    rc = lib.mbnb_quantize_4bit(None, 0, 4, 64, 100, 64, 0, None, None, None, None)
+    assert rc == -2 and b"cols_padded" in lib.mbnb_last_error()
+    rc = lib.mbnb_quantize_4bit(None, 7, 4, 64, 64, 64, 0, None, None, None, None)
+    assert rc == -1
+    rc = lib.mbnb_matmul_4bit(None, 4, 64, None, None, 8, 64, 64, 0, 0, None, 0, None, None)
+    assert rc == -1 and b"absmax" in lib.mbnb_last_error()
+    desc = _native.AbsmaxDesc(None, 16, None, 256)  # int8 absmax without absmax2
+    rc = lib.mbnb_dequantize_4bit(None, ctypes.byref(desc), 1, 64, 64, 64, 0, 0, None, None)
+    assert rc == -1 and b"absmax2" in lib.mbnb_last_error()
+    # empty problems are a no-op success
+    assert lib.mbnb_quantize_rowwise(None, 0, 0, 128, None, None, None) == 0
+    assert lib.mbnb_matmul_int8(None, None, None, None, 0, 16, 16, 0, None, None, None) == 0
+    with pytest.raises(RuntimeError, match="status -1"):
+        _native.check(-1, "unit")
+
+
+def test_product_has_no_cpu_path_and_never_imports_the_oracle():
+    import mps_bitsandbytes_amd as bnb
+    with pytest.raises(ValueError, match="requires tensor on a 'cuda'"):
+        bnb.quantize_nf4(torch.zeros(4, 64))
+    with pytest.raises(ValueError, match="requires tensor on a 'cuda'"):
+        bnb.quantize_rowwise(torch.zeros(4, 64))
+    with pytest.raises(ValueError, match="requires tensor on a 'cuda'"):
+        bnb.dequantize_blockwise(torch.zeros(4, dtype=torch.int8), absmax=torch.ones(1))
+    pkg = os.path.join(ROOT, "mps_bitsandbytes_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(import|from)\s+oracle\b", src, flags=re.M), f"{f} imports the oracle"
+                assert "liboracle" not in src, f"{f} references the oracle library"
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_native, "_lib", None)
+    monkeypatch.setattr(_native, "_load_error", None)
+    monkeypatch.setattr(_native, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no Python fallback"):
+        _native.lib()
+    assert _native.available() is False
