@@ -1,0 +1,274 @@
+#!/usr/bin/env python3
+"""
+bench.py — throughput of the fused NF4 dequant + matmul hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch: Linear4bit-style fused NF4 dequant + matmul,
+weight 4096x4096 (bf16-origin, blocksize 64), M = 4096 rows per GPU, bf16 activations, inputs
+resident in HBM.  With N > 1 the weight is replicated, every rank owns 4096 rows of a global
+batch of 4096*N (BASELINE configs[4] at N = 8: M = 32768) and the step ends with an RCCL
+all-gather of the output shards over xGMI (weak scaling).
+
+Rank 0 prints ONE JSON line: metric/value per the driver contract plus
+  "roofline"     the dominant kernel (k_gemm_decode, MFMA-bound): algorithmic flops per launch /
+                 average launch duration measured with HIP events on the launching stream
+  "cpu_baseline" the CPU oracle (a port of the reference's CPU path) timed on this box's host
+                 cores on a bounded row-sample of the same workload
+  "gemv"         the M = 1 decode shape of the metric (HBM-bound), rotating over 64 distinct
+                 layers (605 MB > 256 MB Infinity Cache), with its own roofline fraction.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "int8": 5000.0}   # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="nf4_m4096",
+                    choices=["nf4_m4096", "nf4dq_ffn", "int8_4096", "nf4_m1"],
+                    help="nf4_m4096 = the BASELINE metric (default); the others are BASELINE configs 3, 4 and 2")
+    ap.add_argument("--no-gather", action="store_true", help="N>1: skip the output all-gather (GEMM-only scaling)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gemv", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
+    return ap.parse_args()
+
+
+def event_time_ms(fn, steps):
+    """Average duration of fn() over `steps` back-to-back launches, HIP events on the current stream."""
+    st = torch.cuda.current_stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(steps):
+        fn()
+    e1.record(st)
+    e1.synchronize()
+    return e0.elapsed_time(e1) / steps
+
+
+def cpu_baseline(args, M, N, K, blocksize, compress, dtype):
+    """The oracle's matmul_4bit (dequantize -> f32-accumulate GEMM, the reference's CPU algorithm)
+    on the host cores, on the first rows of the same workload; rows chosen for ~cpu_seconds."""
+    import oracle
+    from mps_bitsandbytes_amd import synthetic
+    threads = oracle.num_threads()
+    W = synthetic.normal((N, K), dtype, seed=1234)
+    packed, absmax, st2 = oracle.quantize_4bit(W, blocksize, "nf4", compress)
+    X = synthetic.normal((256, K), dtype, seed=4321)
+    t0 = time.perf_counter()
+    oracle.matmul_4bit(X[:32], packed, absmax, (N, K), blocksize, "nf4", dtype, None, None, st2)
+    t_small = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    oracle.matmul_4bit(X, packed, absmax, (N, K), blocksize, "nf4", dtype, None, None, st2)
+    t_256 = time.perf_counter() - t0
+    per_row = max((t_256 - t_small) / (256 - 32), 1e-6)
+    fixed = max(t_small - 32 * per_row, 0.0)
+    rows = int(max(256, min(M, (args.cpu_seconds - fixed) / per_row)))
+    rows = (rows // 64) * 64
+    Xs = synthetic.normal((rows, K), dtype, seed=4321)
+    t0 = time.perf_counter()
+    oracle.matmul_4bit(Xs, packed, absmax, (N, K), blocksize, "nf4", dtype, None, None, st2)
+    dt = time.perf_counter() - t0
+    return {"value": round(2.0 * rows * N * K / dt / 1e12, 5), "unit": "TFLOP/s", "cores": threads, "kind": "port",
+            "sample": f"first {rows} of {M} rows of the same batch (full {N}x{K} weight dequantized once), "
+                      f"{dt:.1f} s, OpenMP {threads} threads, host has {os.cpu_count()} logical cpus"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if not torch.cuda.is_available():
+        print(json.dumps({"error": "no GPU visible; bench.py measures the HIP path only"}))
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import mps_bitsandbytes_amd as bnb
+    from mps_bitsandbytes_amd import _native, synthetic
+    from mps_bitsandbytes_amd.sharding import row_shard
+    _native.lib()  # fail loudly when the HIP library is missing
+
+    wl = args.workload
+    if wl == "nf4_m4096":
+        M, N, K, dt, compress, name = 4096, 4096, 4096, torch.bfloat16, False, "bf16"
+    elif wl == "nf4dq_ffn":
+        M, N, K, dt, compress, name = 4096, 11008, 4096, torch.bfloat16, True, "bf16"
+    elif wl == "nf4_m1":
+        M, N, K, dt, compress, name = 1, 4096, 4096, torch.float16, False, "f16"
+    else:
+        M, N, K, dt, compress, name = 4096, 4096, 4096, torch.float16, False, "int8"
+
+    M_global = M * world
+    s_row, e_row = row_shard(M_global, rank, world)
+    g = torch.Generator(device=dev)
+    g.manual_seed(4321 + rank)
+
+    out = {"metric": None, "value": None, "unit": None, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": name,
+           "data": "synthetic"}
+
+    gathered = None
+    if wl in ("nf4_m4096", "nf4dq_ffn", "nf4_m1"):
+        std = 1.0 if wl != "nf4dq_ffn" else 0.02
+        W = (torch.randn(N, K, generator=g, device=dev, dtype=torch.float32) * std).to(dt)
+        if wl == "nf4_m1":
+            # rotate over 64 distinct layers so the weights come from HBM, not the Infinity Cache
+            layers = []
+            for i in range(64):
+                Wi = (torch.randn(N, K, generator=g, device=dev, dtype=torch.float32)).to(dt)
+                layers.append(bnb.quantize_nf4(Wi, blocksize=64))
+                del Wi
+            X = torch.randn(1, K, generator=g, device=dev, dtype=torch.float32).to(dt)
+            ys = torch.empty(64, N, dtype=dt, device=dev)
+
+            def step():
+                for p, st in layers:
+                    bnb.matmul_4bit(X, p, st)
+            flops_per_step = 2.0 * N * K * 64
+            bytes_per_launch = N * K // 2 + N * (K // 64) * 4 + K * 2 + N * 2   # 9 453 568 B
+        else:
+            packed, state = bnb.quantize_nf4(W, blocksize=64, compress_statistics=compress)
+            del W
+            X = torch.randn(e_row - s_row, K, generator=g, device=dev, dtype=torch.float32).to(dt)
+            if distributed and not args.no_gather:
+                gathered = torch.empty(M_global, N, dtype=dt, device=dev)
+
+            def step():
+                y = bnb.matmul_4bit(X, packed, state)
+                if gathered is not None:
+                    dist.all_gather_into_tensor(gathered, y)
+            flops_per_step = 2.0 * M * N * K
+    else:
+        A = torch.randint(-127, 128, (M, K), generator=g, device=dev, dtype=torch.int8)
+        B = torch.randint(-127, 128, (K, N), generator=g, device=dev, dtype=torch.int8)
+        sa = torch.rand(M, generator=g, device=dev) + 0.5
+        sb = torch.rand(N, generator=g, device=dev) + 0.5
+
+        def step():
+            bnb.matmul_int8(A, B, sa, sb, torch.float16)
+        flops_per_step = 2.0 * M * N * K
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_name = _native.last_kernel()
+
+    # kernel-only launch duration (no gather, no host gaps beyond back-to-back launches)
+    if wl == "nf4_m1":
+        kern_ms = event_time_ms(step, max(1, args.steps // 4)) / 64
+    elif wl == "int8_4096":
+        kern_ms = event_time_ms(step, args.steps)
+    else:
+        kern_ms = event_time_ms(lambda: bnb.matmul_4bit(X, packed, state), args.steps)
+
+    ms_per_step = elapsed / args.steps * 1e3
+    total_flops = flops_per_step * world
+    out["ms_per_step"] = round(ms_per_step, 5)
+    out["config"] = {"workload": {"nf4_m4096": "Linear4bit-style fused NF4 dequant+matmul, weight 4096x4096 bf16-origin bs64, M=4096 rows per GPU",
+                                  "nf4dq_ffn": "fused NF4 + double-quant absmax, weight 11008x4096 bf16 bs64, M=4096",
+                                  "int8_4096": "rowwise INT8 matmul_int8 4096x4096x4096 on int8 MFMA",
+                                  "nf4_m1": "fused NF4 dequant+GEMV, weight 4096x4096 fp16 bs64, M=1, rotating over 64 layers"}[wl],
+                     "global_rows": M_global, "rows_per_gpu": M, "N": N, "K": K,
+                     "parallelism": f"rows sharded x{world}, weights replicated" + (", all-gather of outputs (RCCL)" if gathered is not None else ""),
+                     "kernel": kernel_name}
+    if wl == "nf4_m1":
+        gbs = bytes_per_launch / (kern_ms * 1e-3) / 1e9
+        out["metric"] = "effective GB/s, fused NF4 dequant+GEMV 4096x4096 M=1 (HBM, 64 rotating layers)"
+        out["value"] = round(bytes_per_launch * 64 * world / (elapsed / args.steps) / 1e9, 2)
+        out["unit"] = "GB/s"
+        out["roofline"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                           "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None,
+                           "kernel_us": round(kern_ms * 1e3, 3)}
+    else:
+        tflops = total_flops / (elapsed / args.steps) / 1e12
+        peak = PEAK_TFLOPS[name]
+        kern_tflops = flops_per_step / (kern_ms * 1e-3) / 1e12
+        out["metric"] = ("effective bf16 TFLOPS, fused NF4 dequant+matmul 4096x4096 @ M=4096" if wl == "nf4_m4096"
+                         else f"effective TFLOPS, {wl}")
+        out["value"] = round(tflops, 2)
+        out["unit"] = "TFLOP/s"
+        out["roofline"] = {"bound": "mfma", "achieved": round(kern_tflops, 2), "peak": peak, "unit": "TFLOP/s",
+                           "frac": round(kern_tflops / peak, 4), "traffic": None,
+                           "kernel_us": round(kern_ms * 1e3, 2)}
+
+    if rank == 0 and wl == "nf4_m4096":
+        if not args.no_gemv:
+            # the M = 1 half of the metric: HBM-bound decode shape, 64 rotating layers
+            layers = []
+            for i in range(64):
+                Wi = torch.randn(N, K, generator=g, device=dev, dtype=torch.float32).to(dt)
+                layers.append(bnb.quantize_nf4(Wi, blocksize=64))
+                del Wi
+            x1 = torch.randn(1, K, generator=g, device=dev, dtype=torch.float32).to(dt)
+
+            def gemv_pass():
+                for p, st in layers:
+                    bnb.matmul_4bit(x1, p, st)
+            for _ in range(3):
+                gemv_pass()
+            torch.cuda.synchronize()
+            us = event_time_ms(gemv_pass, 10) / 64 * 1e3
+            nbytes = N * K // 2 + N * (K // 64) * 4 + K * 2 + N * 2
+            gbs = nbytes / (us * 1e-6) / 1e9
+            out["gemv"] = {"workload": "fused NF4 dequant+GEMV 4096x4096 M=1 bf16, 64 rotating layers (605 MB)",
+                           "kernel": _native.last_kernel(), "us_per_layer": round(us, 3), "bytes_per_layer": nbytes,
+                           "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                        "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None}}
+            del layers
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args, M, N, K, 64, compress, dt)
+    if rank == 0 and wl == "nf4_m4096":
+        prof = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(prof):
+            try:
+                out["roofline"]["traffic"] = json.load(open(prof)).get("k_gemm_decode_bytes_per_launch")
+            except Exception:
+                pass
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
