@@ -11,7 +11,9 @@
 // Numerics follow the reference CPU branch (functional.py:752-773): the decoded weight is
 // rounded to the weight dtype before the contraction, accumulation is f32, one rounding of the
 // result to the weight dtype, then a cast to the requested output dtype.
-#include "gemm_tile.h"
+#include <type_traits>
+
+#include "gemm256.h"
 
 namespace mbnb {
 
@@ -87,17 +89,17 @@ template <> struct Dot2<bf16_t> {
     }
 };
 
-template <typename T, typename OutT, int QT, bool NESTED, int MT, int NR>
+// KU k-steps of 2048 (64 lanes x 32 k) are processed per loop trip with ALL their loads issued
+// before the first use; out-of-range chunks load from a clamped address with a zeroed absmax
+// (no branch or select between a load and its use: that makes hipcc wait vmcnt(0) per load).
+template <typename T, typename OutT, int QT, bool NESTED, int MT, int NR, int KU>
 __global__ __launch_bounds__(256) void k_gemv4(const T *__restrict__ X, const uint8_t *__restrict__ packed, AbsmaxView am,
                                               const T *__restrict__ bias, OutT *__restrict__ out, int64_t M, int64_t N,
                                               int64_t K, int64_t K_weight, int bs_shift) {
     __shared__ float lut[16];
-    fill_code_lut<QT>(lut, threadIdx.x);
-    __syncthreads();
     const int lane = threadIdx.x & 63;
     const int64_t n0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * NR;
     const int64_t m0 = (int64_t)blockIdx.y * MT;
-    if (n0 >= N) return;
     const int64_t nblk = K_weight >> bs_shift;
     const int64_t row_bytes = K_weight >> 1;
 
@@ -107,40 +109,67 @@ __global__ __launch_bounds__(256) void k_gemv4(const T *__restrict__ X, const ui
 #pragma unroll
         for (int i = 0; i < MT; i++) acc[r][i] = 0.0f;
 
-    for (int64_t k0 = (int64_t)lane * 32; k0 < K; k0 += 2048) {
-        u32x4 wq[NR];
-        float a[NR];
+    const uint8_t *wrow[NR];
+    int64_t arow[NR];
 #pragma unroll
-        for (int r = 0; r < NR; r++) {
-            const int64_t n = (n0 + r < N) ? n0 + r : N - 1;
-            wq[r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(packed + n * row_bytes + (k0 >> 1)));
-            a[r] = load_absmax<NESTED>(am, n * nblk + (k0 >> bs_shift));
-        }
-        u32x4 xv[MT][4];
+    for (int r = 0; r < NR; r++) {
+        const int64_t n = (n0 + r < N) ? n0 + r : N - 1;
+        wrow[r] = packed + n * row_bytes;
+        arow[r] = n * nblk;
+    }
+    const T *xrow[MT];
 #pragma unroll
-        for (int i = 0; i < MT; i++) {
-            const int64_t m = (m0 + i < M) ? m0 + i : M - 1;
+    for (int i = 0; i < MT; i++) xrow[i] = X + ((m0 + i < M) ? m0 + i : M - 1) * K;
+
+    fill_code_lut<QT>(lut, threadIdx.x);
+    __syncthreads();
+    for (int64_t kbase = 0; kbase < K; kbase += 2048 * KU) {
+        u32x4 wq[KU][NR];
+        float a[KU][NR];
+        float vf[KU];
+        u32x4 xv[KU][MT][4];
 #pragma unroll
-            for (int c = 0; c < 4; c++) {
-                const int64_t k = k0 + 8 * c;
-                xv[i][c] = (k + 8 <= K) ? *reinterpret_cast<const u32x4 *>(X + m * K + k) : u32x4{0, 0, 0, 0};
+        for (int u = 0; u < KU; u++) {
+            // K % 32 == 0 here, so a lane's 32-k chunk is entirely inside or outside [0, K).  Outside:
+            // load from k = 0 (in bounds) and zero the absmax, so the products vanish -- no branch,
+            // no select between a load and its use.
+            const int64_t k0 = kbase + u * 2048 + lane * 32;
+            const bool wvalid = k0 < K;
+            const int64_t kc = wvalid ? k0 : 0;
+            vf[u] = wvalid ? 1.0f : 0.0f;
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                wq[u][r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(wrow[r] + (kc >> 1)));
+                a[u][r] = load_absmax<NESTED>(am, arow[r] + (kc >> bs_shift));
             }
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+#pragma unroll
+                for (int i = 0; i < MT; i++) xv[u][i][c] = *reinterpret_cast<const u32x4 *>(xrow[i] + kc + 8 * c);
         }
+        // keep every load above issued before anything waits on one of them
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int r = 0; r < NR; r++) {
+        for (int u = 0; u < KU; u++)
 #pragma unroll
-            for (int c = 0; c < 4; c++) {
-                const uint32_t w = wq[r][c];
+            for (int r = 0; r < NR; r++) a[u][r] *= vf[u];
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const float lo = lut[(w >> (8 * j)) & 15] * a[r];
-                    const float hi = lut[(w >> (8 * j + 4)) & 15] * a[r];
-                    const uint32_t wp = pack2<T>(lo, hi);
+        for (int u = 0; u < KU; u++)
 #pragma unroll
-                    for (int i = 0; i < MT; i++) acc[r][i] = Dot2<T>::run(wp, xv[i][c][j], acc[r][i]);
+            for (int r = 0; r < NR; r++) {
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const uint32_t w = wq[u][r][c];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const float lo = lut[(w >> (8 * j)) & 15] * a[u][r];
+                        const float hi = lut[(w >> (8 * j + 4)) & 15] * a[u][r];
+                        const uint32_t wp = pack2<T>(lo, hi);
+#pragma unroll
+                        for (int i = 0; i < MT; i++) acc[r][i] = Dot2<T>::run(wp, xv[u][i][c][j], acc[r][i]);
+                    }
                 }
             }
-        }
     }
 #pragma unroll
     for (int r = 0; r < NR; r++)
@@ -175,20 +204,40 @@ static int launch_matmul4(const void *A, int64_t M, int64_t K, const uint8_t *pa
     const bool fast_layout = is16 && blocksize >= 32 && (K_weight % 32 == 0) && (K % 8 == 0) && aligned16(A) &&
                              aligned16(packed);
     if constexpr (is16) {
-        if (fast_layout && M <= 16) {
-            constexpr int NR = 2;
-            const unsigned gx = (unsigned)((N + 4 * NR - 1) / (4 * NR));
+        if (fast_layout && M <= 16 && (K % 32 == 0)) {
             const int sh = ilog2(blocksize);
-#define MBNB_GEMV(MT)                                                                                              \
-    hipLaunchKernelGGL((k_gemv4<T, OutT, QT, NESTED, MT, NR>), dim3(gx, (unsigned)((M + MT - 1) / MT)), dim3(256), 0, \
-                       st, x, packed, am, b, o, M, N, K, K_weight, sh)
-            if (M == 1) MBNB_GEMV(1);
-            else if (M == 2) MBNB_GEMV(2);
-            else if (M <= 4) MBNB_GEMV(4);
-            else MBNB_GEMV(8);
+#define MBNB_GEMV(MT, NR, KU)                                                                                       \
+    hipLaunchKernelGGL((k_gemv4<T, OutT, QT, NESTED, MT, NR, KU>),                                                   \
+                       dim3((unsigned)((N + 4 * NR - 1) / (4 * NR)), (unsigned)((M + MT - 1) / MT)), dim3(256), 0, st, x, \
+                       packed, am, b, o, M, N, K, K_weight, sh)
+            if (M == 1) MBNB_GEMV(1, 2, 2);
+            else if (M == 2) MBNB_GEMV(2, 2, 2);
+            else if (M <= 4) MBNB_GEMV(4, 2, 1);
+            else MBNB_GEMV(8, 1, 1);
 #undef MBNB_GEMV
             set_kernel_name("gemv");
             return check_launch("matmul_4bit(gemv)");
+        }
+        if (fast_layout && (K % 64 == 0) && ((M + 255) / 256) * ((N + 255) / 256) >= 96) {
+            // large problems: 256 x 256 tiles, one workgroup per CU
+            using P = Q4ProducerRT<T, NESTED>;
+            typename P::Params wp{packed, am, N, K_weight, K_weight / blocksize, ilog2(blocksize), QT};
+            auto kern = k_gemm256<T, P>;
+            static bool attr_done256 = false;
+            if (!attr_done256) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS);
+                if (e != hipSuccess) {
+                    set_error("matmul_4bit: hipFuncSetAttribute(256) failed: %s", hipGetErrorString(e));
+                    return (int)e;
+                }
+                attr_done256 = true;
+            }
+            const int64_t tiles = ((M + 255) / 256) * ((N + 255) / 256);
+            int od = sizeof(OutT) == 4 ? MBNB_F32 : (std::is_same<OutT, f16_t>::value ? MBNB_F16 : MBNB_BF16);
+            hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(512), G256_LDS, st, x, wp, b, static_cast<void *>(o), od, M, N, K);
+            set_kernel_name("mfma256");
+            return check_launch("matmul_4bit(mfma256)");
         }
         if (fast_layout) {
             using P = Q4Producer<T, QT, NESTED>;

@@ -157,6 +157,20 @@ def test_matmul_mfma_path(shape, dt):
     assert "mfma" in _oracle_vs_gpu_matmul(M, N, K, dt, seed=20 + M)
 
 
+@pytest.mark.parametrize("case", [
+    dict(M=2560, N=2560, K=256, dt=torch.bfloat16),
+    dict(M=2500, N=2600, K=192, dt=torch.float16),                       # ragged M and N edges
+    dict(M=2500, N=2600, K=128, dt=torch.bfloat16, qt="fp4", cs=True, bs=32),
+    dict(M=3000, N=2304, K=384, dt=torch.float16, cs=True, bs=128, cd=torch.float32),
+    dict(M=2304, N=3000, K=64, dt=torch.float16, cd=torch.bfloat16),      # single k-step
+])
+def test_matmul_mfma256_path(case):
+    """The 256x256 one-workgroup-per-CU kernel (dispatched for >= 96 tiles)."""
+    c = dict(case)
+    kern = _oracle_vs_gpu_matmul(c.pop("M"), c.pop("N"), c.pop("K"), c.pop("dt"), seed=25, **c)
+    assert kern == "mfma256"
+
+
 @pytest.mark.parametrize("qt", ["nf4", "fp4"])
 @pytest.mark.parametrize("cs", [False, True])
 @pytest.mark.parametrize("bs", [32, 64, 128, 256])
@@ -177,7 +191,10 @@ def test_matmul_generic_path_odd_shapes():
 
 def test_matmul_k_padded_fast_path():
     """K a multiple of 8 but not of the blocksize: K_weight > K (functional.py:219-221)."""
-    assert _oracle_vs_gpu_matmul(1, 64, 72, torch.float16, seed=50) == "gemv"
+    assert _oracle_vs_gpu_matmul(1, 64, 96, torch.float16, seed=50) == "gemv"      # K_weight = 128
+    assert _oracle_vs_gpu_matmul(2, 64, 4160, torch.float16, seed=52) == "gemv"    # ragged last k-step
+    assert _oracle_vs_gpu_matmul(5, 64, 2080, torch.bfloat16, seed=53) == "gemv"
+    assert _oracle_vs_gpu_matmul(1, 64, 72, torch.float16, seed=54) == "generic"   # K % 32 != 0
     assert "mfma" in _oracle_vs_gpu_matmul(64, 128, 200, torch.bfloat16, seed=51)
 
 
