@@ -17,6 +17,8 @@
 // v_mfma_f32_32x32x16 (weight tile = MFMA A operand, activation tile = B operand).
 #pragma once
 
+#include <type_traits>
+
 #include "gemm_tile.h"
 
 namespace mbnb {
@@ -40,6 +42,7 @@ template <typename T, bool NESTED> struct Q4ProducerRT {
         int64_t nblk;
         int bs_shift;
         int qt;
+        int bs2_shift;  // log2(absmax blocksize2) for the nested form (k_gemm256p only)
     };
     struct Regs {
         u32x4 w;
@@ -251,6 +254,633 @@ __global__ __launch_bounds__(512, 2) void k_gemm256(const T *__restrict__ X, typ
                 else store4(static_cast<float *>(out_v) + m * N + n, v, n, N);
             }
         }
+}
+
+
+// =====================================================================================
+// k_gemm256p — software-pipelined 4-bit variant of k_gemm256 (same tile and wave grid).
+//
+// LDS map: static [code table 1K]; dynamic [A0 32K][A1 32K][B0 32K][B1 32K][raw0][raw1]  (A = activation image,
+// B = decoded weight image; every image keeps the gemm_tile.h row swizzle).  A and B halves are
+// 64 KiB apart so that one base VGPR + a 16-bit immediate reaches both stages of an image.
+//
+// Every global access in the main loop is an LDS-DMA (global_load_lds), so all vector-memory
+// waits are hand-counted `s_waitcnt vmcnt(N)` and loads stay in flight across the barrier:
+//   * activations A(j+2): 4 x 1 KiB pieces per wave -> stage j&1, issued right after barrier j;
+//   * the thread's own packed weights + absmax for tile j+3 ("raw"): 16 B + 4 B per lane into a
+//     per-wave raw slot (double-buffered), read back by the SAME lane two k-steps later -- no
+//     VGPR-destination loads, hence no compiler-inserted vmcnt(0).
+// One barrier per k-step, placed between MFMA groups 2 and 3 (a group = 8 MFMAs = one k16 slice):
+// groups 0..2 run on fragments of stage c, the decoded weights of tile j+1 go to stage c^1 during
+// groups 0/1, and group 3 runs while the first fragments of stage c^1 are already being read.
+// Inside a group the MFMAs are issued FIRST, then the decode and the next group's fragment
+// reads, so LDS latency and decode VALU sit in the shadow of the matrix pipe.
+//
+// VMEM program order per wave: ... [A(j+1) x4, raw(j+2) x R] [A(j+2) x4, raw(j+3) x R] ...
+//   before decoding tile j+1 (group 0 of step j): raw(j+1) done  <=> vmcnt(4 + R)
+//   before barrier j:                            A(j+1)  done  <=> vmcnt(R)
+// =====================================================================================
+// one v_bfe_u32 (hipcc otherwise emits shift + and for a constant-position field)
+__device__ __forceinline__ uint32_t bfe_u32(uint32_t x, int off, int width) {
+    uint32_t r;
+    asm("v_bfe_u32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "n"(off), "n"(width));
+    return r;
+}
+
+constexpr int P_A = 0, P_B = 65536, P_RAW = 131072;  // offsets inside the dynamic LDS region
+constexpr int P_IMG = 32768;  // bytes per image stage
+
+#define MBNB_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+#ifdef MBNB_ABLATION
+// debug stamps (diagnostic builds only): [set][event] shader-clock values of workgroup 0
+__device__ unsigned long long g_dbg_stamps[2][1024];
+#endif
+#define MBNB_NOP4() do {} while (0)
+#define MBNB_NOP2() do {} while (0)
+
+template <typename T, bool NESTED, int ablate = 0>
+__global__ __launch_bounds__(512, 2) void k_gemm256p(const T *__restrict__ X, typename Q4ProducerRT<T, NESTED>::Params wp,
+                                                     const T *__restrict__ bias, void *__restrict__ out_v, int out_dtype,
+                                                     int64_t M, int64_t N, int64_t K) {
+    using Frag = typename Mfma<T>::frag;
+    // `ablate` (compile-time, debug only; -DMBNB_ABLATION builds the variants and MBNB_ABLATE selects one):
+    // timing-only kernels that skip 1 = activation DMA, 2 = raw DMA, 4 = decode, 8 = MFMAs,
+    // 16 = fragment reads inside the main loop.  Production kernels are ablate = 0.
+    // LDS-DMA instructions per wave and k-step for the raw slot: packed + absmax (+ absmax2 when nested)
+    constexpr int RAW_BYTES = 8192 + 2048 + (NESTED ? 2048 : 0);
+    // the code table is a STATIC LDS object: its address is a compile-time constant, so a lookup is
+    // `ds_read_b32 v, v_idx4 offset:<table>` with no address add (a table inside the dynamic region
+    // costs one v_add per lookup).  256 floats keep the dynamic region 1 KiB aligned.
+    __shared__ __attribute__((aligned(1024))) float s_lut[256];
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave >> 2, wm = wave & 3;
+
+    const int64_t tiles_m = (M + 255) >> 8, tiles_n = (N + 255) >> 8;
+    const int64_t nwg = tiles_m * tiles_n;
+    int64_t bid = blockIdx.x;
+    {
+        const int64_t q = nwg / 8, r = nwg % 8, xcd = bid % 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+    }
+    int64_t tm, tn;
+    if ((tiles_m % 4 == 0) && (tiles_n % 8 == 0)) {
+        const int64_t patch = bid >> 5, within = bid & 31;
+        const int64_t patches_m = tiles_m >> 2;
+        tm = (patch % patches_m) * 4 + (within & 3);
+        tn = (patch / patches_m) * 8 + (within >> 2);
+    } else {
+        tm = bid % tiles_m;
+        tn = bid / tiles_m;
+    }
+    const int64_t m0 = tm << 8, n0 = tn << 8;
+
+    fill_code_lut_rt(s_lut, tid, wp.qt);
+
+    // ---- activation pieces: wave w moves pieces 4w..4w+3 (8 rows x 128 B each), swizzle on the source
+    const T *a_src[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int row = 8 * (wave * 4 + i) + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        int64_t m = m0 + row;
+        m = m < M ? m : M - 1;
+        a_src[i] = X + m * K + 8 * c;
+    }
+    auto issue_a = [&](int stage, int64_t k0) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            auto g = (const __attribute__((address_space(1))) void *)(a_src[i] + k0);
+            auto l = (__attribute__((address_space(3))) void *)(smem + P_A + stage * P_IMG + (wave * 4 + i) * 1024);
+            __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
+        }
+    };
+
+    // ---- weight decode role of this thread: rows 32*wave .. 32*wave+31 belong to this wave.
+    // lane -> (row, k-half) chosen so that the 8 lanes of a ds_write_b128 group hit 8 different
+    // swizzled chunks: lanes 0-7 even rows, 8-15 odd rows (half 0); 16-31 the same for half 1.
+    const int l32 = lane & 31;
+    const int b_row = 32 * wave + 16 * (lane >> 5) + 2 * (l32 & 7) + ((l32 >> 3) & 1);
+    const int b_half = l32 >> 4;
+    int64_t bn = n0 + b_row;
+    bn = bn < N ? bn : N - 1;
+    const uint8_t *p_src = wp.packed + ((bn * wp.K_weight) >> 1) + 16 * b_half;
+    const int64_t am_row = bn * wp.nblk;
+    const int raw_lane = P_RAW + wave * 1024 + lane * 16;        // this lane's packed 16 B
+    const int raw_am = P_RAW + 8192 + wave * 256 + lane * 4;     // absmax f32 (or the dword holding the int8 code)
+    const int raw_am2 = P_RAW + 8192 + 2048 + wave * 256 + lane * 4;
+    auto issue_raw = [&](int rs, int64_t k0) {
+        char *base = smem + P_RAW + rs * RAW_BYTES;
+        {
+            auto g = (const __attribute__((address_space(1))) void *)(p_src + (k0 >> 1));
+            auto l = (__attribute__((address_space(3))) void *)(base + wave * 1024);
+            __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
+        }
+        const int64_t ai = am_row + ((k0 + 32 * b_half) >> wp.bs_shift);
+        if constexpr (!NESTED) {
+            auto g = (const __attribute__((address_space(1))) void *)(wp.am.f32 + ai);
+            auto l = (__attribute__((address_space(3))) void *)(base + 8192 + wave * 256);
+            __builtin_amdgcn_global_load_lds(g, l, 4, 0, 0);
+        } else {
+            // the aligned dword that contains int8 code `ai`, and its absmax2 (one per 2^bs2_shift codes)
+            auto g = (const __attribute__((address_space(1))) void *)(wp.am.i8 + (ai & ~(int64_t)3));
+            auto l = (__attribute__((address_space(3))) void *)(base + 8192 + wave * 256);
+            __builtin_amdgcn_global_load_lds(g, l, 4, 0, 0);
+            auto g2 = (const __attribute__((address_space(1))) void *)(wp.am.am2 + (ai >> wp.bs2_shift));
+            auto l2 = (__attribute__((address_space(3))) void *)(base + 8192 + 2048 + wave * 256);
+            __builtin_amdgcn_global_load_lds(g2, l2, 4, 0, 0);
+        }
+    };
+    u32x4 rw;
+    float ram;
+    auto load_raw = [&](int rs, int64_t k0) {
+        const char *base = smem + rs * RAW_BYTES;
+        rw = *reinterpret_cast<const u32x4 *>(base + raw_lane);
+        if constexpr (!NESTED) {
+            ram = *reinterpret_cast<const float *>(base + raw_am);
+        } else {
+            const int64_t ai = am_row + ((k0 + 32 * b_half) >> wp.bs_shift);
+            const uint32_t word = *reinterpret_cast<const uint32_t *>(base + raw_am);
+            const float q = (float)(int)(int8_t)(word >> (8 * (int)(ai & 3)));
+            const float a2 = *reinterpret_cast<const float *>(base + raw_am2);
+            ram = q * (a2 / 127.0f);  // dequantize_blockwise arithmetic (functional.py:592-594)
+        }
+    };
+    int bw_off[4];  // byte offsets of this thread's 4 output chunks inside stage 0 of the B image
+#pragma unroll
+    for (int d = 0; d < 4; d++) bw_off[d] = P_B + swz_off(b_row, 4 * b_half + d);
+    // decode quarter d (8 k) of the raw registers into B image `stage`
+    auto emit_q = [&](int d, int stage) {
+        const uint32_t w = rw[d];
+        // byte offsets (4 * idx) into the code table: odd nibbles sit at bits 8j+4..8j+7, so a 6-bit
+        // field at 8j+2 of (w & 0xF0F0F0F0) is idx*4; even nibbles after (w << 2) & 0x3C3C3C3C.
+        const uint32_t wo = w & 0xF0F0F0F0u;
+        const uint32_t we = (w << 2) & 0x3C3C3C3Cu;
+        const char *lutb = reinterpret_cast<const char *>(s_lut);
+        u32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t ie = bfe_u32(we, 8 * j, 8);
+            const uint32_t io = bfe_u32(wo, 8 * j + 2, 6);
+            const float lo = *reinterpret_cast<const float *>(lutb + ie) * ram;
+            const float hi = *reinterpret_cast<const float *>(lutb + io) * ram;
+            o[j] = pack2<T>(lo, hi);
+        }
+        *reinterpret_cast<u32x4 *>(smem + stage * P_IMG + bw_off[d]) = o;
+    };
+
+    // ---- fragment read offsets: per MFMA group s (chunk 2s + fh, swizzled by the row)
+    const int fr = lane & 31, fh = lane >> 5;
+    int fw[4], fx[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        const int f = fr * ROW_BYTES + (((2 * s + fh) ^ ((fr >> 1) & 7)) << 4);
+        fw[s] = P_B + wn * 128 * ROW_BYTES + f;
+        fx[s] = P_A + wm * 64 * ROW_BYTES + f;
+    }
+    auto read_frags = [&](int stage, int s, Frag (&wf)[4], Frag (&xf)[2]) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) wf[i] = *reinterpret_cast<const Frag *>(smem + fw[s] + stage * P_IMG + i * 32 * ROW_BYTES);
+#pragma unroll
+        for (int j = 0; j < 2; j++) xf[j] = *reinterpret_cast<const Frag *>(smem + fx[s] + stage * P_IMG + j * 32 * ROW_BYTES);
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
+    auto mfma_group = [&](const Frag (&wf)[4], const Frag (&xf)[2]) {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) acc[i][j] = Mfma<T>::run(wf[i], xf[j], acc[i][j]);
+    };
+
+    const int64_t nk = K >> 6;
+    const int64_t k_last = (nk - 1) << 6;
+    auto kclamp = [&](int64_t t) { return t < nk ? t << 6 : k_last; };
+
+    // ---- prologue: stage 0 <- tile 0, raw slots <- tiles 0 (then 2) and 1, A(1) in flight
+    issue_a(0, 0);
+    issue_raw(0, 0);
+    issue_raw(1, kclamp(1));
+    MBNB_VMCNT(0);
+    __syncthreads();  // code table, A(0) and this wave's raw(0), raw(1) visible
+    load_raw(0, 0);
+#pragma unroll
+    for (int d = 0; d < 4; d++) emit_q(d, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    issue_a(1, kclamp(1));
+    issue_raw(0, kclamp(2));
+    __builtin_amdgcn_s_barrier();  // decoded B(0) visible (each wave waited for its own LDS writes)
+    asm volatile("" ::: "memory");
+    Frag wfA[4], xfA[2], wfB[4], xfB[2];
+    read_frags(0, 0, wfA, xfA);
+
+    // one k-step with compile-time stage parity C (stage C holds tile j, stage C^1 receives tile j+1)
+    auto kstep = [&](auto cc, int64_t j) {
+        constexpr int C = decltype(cc)::value, Nn = C ^ 1;
+        // group 0
+        if constexpr (NESTED) MBNB_VMCNT(7); else MBNB_VMCNT(6);  // 4 + R: this wave's raw(j+1) has landed in slot Nn
+        load_raw(Nn, kclamp(j + 1));
+        if constexpr (!(ablate & 8)) mfma_group(wfA, xfA);
+        if constexpr (!(ablate & 4)) { emit_q(0, Nn); emit_q(1, Nn); }
+        if constexpr (!(ablate & 16)) read_frags(C, 1, wfB, xfB);
+        if constexpr (ablate & 1024) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+                if (r >= 6) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // group 1
+        if constexpr (!(ablate & 8)) mfma_group(wfB, xfB);
+        if constexpr (!(ablate & 4)) { emit_q(2, Nn); emit_q(3, Nn); }
+        if constexpr (!(ablate & 16)) read_frags(C, 2, wfA, xfA);
+        if constexpr (ablate & 1024) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+                if (r >= 6) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // group 2
+        if constexpr (!(ablate & 8)) mfma_group(wfA, xfA);
+        if constexpr (!(ablate & 16)) read_frags(C, 3, wfB, xfB);
+        if constexpr (NESTED) MBNB_VMCNT(3); else MBNB_VMCNT(2);  // R: A(j+1) landed (this wave's pieces)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // own decode writes + fragment reads done
+        __builtin_amdgcn_s_barrier();                         // stage Nn complete, stage C free
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        // group 3: refill stage C and raw slot Nn; first fragments of stage Nn
+        if constexpr (!(ablate & 8)) mfma_group(wfB, xfB);
+        if constexpr (!(ablate & 1)) issue_a(C, kclamp(j + 2));
+        if constexpr (!(ablate & 2)) issue_raw(Nn, kclamp(j + 3));
+        if constexpr (!(ablate & 16)) read_frags(Nn, 0, wfA, xfA);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int64_t j = 0; j < nk; j += 2) {
+        kstep(std::integral_constant<int, 0>{}, j);
+        if (j + 1 < nk) kstep(std::integral_constant<int, 1>{}, j + 1);
+    }
+    MBNB_VMCNT(0);
+
+    // ---- epilogue (as k_gemm256)
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int64_t m = m0 + wm * 64 + j * 32 + fr;
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int64_t nn = n0 + wn * 128 + i * 32 + 8 * g + 4 * fh;
+                if (m >= M || nn >= N) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    float s = acc[i][j][4 * g + e];
+                    if (bias != nullptr && nn + e < N) s += to_f32(bias[nn + e]);
+                    v[e] = to_f32(from_f32<T>(s));
+                }
+                if (out_dtype == MBNB_F16) store4(static_cast<f16_t *>(out_v) + m * N + nn, v, nn, N);
+                else if (out_dtype == MBNB_BF16) store4(static_cast<bf16_t *>(out_v) + m * N + nn, v, nn, N);
+                else store4(static_cast<float *>(out_v) + m * N + nn, v, nn, N);
+            }
+        }
+}
+
+// =====================================================================================
+// k_gemm256pp — "ping-pong" schedule of k_gemm256p (same tile, LDS map, DMA staging, decode).
+//
+// Measured on k_gemm256p: its phases add up instead of overlapping (skeleton 31 us + DMA 46 +
+// decode 20 + fragment reads 3 + MFMA 73 = 173 us of a 171 us launch): all 8 waves run the same
+// phase at the same time, so the LDS, VALU and matrix pipes take turns.  Here the two waves that
+// share a SIMD (w and w+4) are kept in OPPOSITE phases: while waves 0-3 issue 16 register-only
+// MFMAs (a 512-cycle matrix segment), waves 4-7 run their memory segment (fragment reads for
+// their next 16 MFMAs, decode of two weight quarters, LDS-DMA issue), then they swap.  A k-step is
+// four slots per wave, each closed by s_barrier:
+//     S0  MFMA k16 groups 0,1 of tile j          (fragments F loaded in the previous S3)
+//     S1  read F <- groups 2,3 of tile j; decode quarters 2,3 of tile j+1 -> stage (j+1)&1;
+//         DMA raw(j+3); wait A(j+1) landed
+//     S2  MFMA groups 2,3 of tile j
+//     S3  read F <- groups 0,1 of tile j+1; load raw(j+2); decode quarters 0,1 of tile j+2 ->
+//         stage j&1; DMA A(j+2) -> stage j&1
+// Waves 4-7 run the same program one slot later (one extra barrier up front, waves 0-3 one extra
+// at the end), so at every slot one wave of each SIMD feeds the matrix pipe.  Stage hand-offs:
+// tile j+1 is complete after both sets finished their S1 of step j, i.e. before either set's S3;
+// stage j&1 is rewritten from S3 of step j on, after both sets' last reads of tile j (their S1).
+// =====================================================================================
+template <typename T, bool NESTED, int ablate = 0>
+__global__ __launch_bounds__(512, 2) void k_gemm256pp(const T *__restrict__ X, typename Q4ProducerRT<T, NESTED>::Params wp,
+                                                      const T *__restrict__ bias, void *__restrict__ out_v, int out_dtype,
+                                                      int64_t M, int64_t N, int64_t K) {
+    using Frag = typename Mfma<T>::frag;
+    constexpr int RAW_BYTES = 8192 + 2048 + (NESTED ? 2048 : 0);
+    __shared__ __attribute__((aligned(1024))) float s_lut[256];
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // the delayed set: waves 4-7 share their SIMDs with waves 0-3 (debug: ablate & 32 -> odd waves, & 64 -> waves 2,3,6,7)
+    const bool delayed = (ablate & 32) ? (wave & 1) != 0 : ((ablate & 64) ? ((wave >> 1) & 1) != 0 : wave >= 4);
+    const int wn = wave >> 2, wm = wave & 3;
+
+    const int64_t tiles_m = (M + 255) >> 8, tiles_n = (N + 255) >> 8;
+    const int64_t nwg = tiles_m * tiles_n;
+    int64_t bid = blockIdx.x;
+    {
+        const int64_t q = nwg / 8, r = nwg % 8, xcd = bid % 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+    }
+    int64_t tm, tn;
+    if ((tiles_m % 4 == 0) && (tiles_n % 8 == 0)) {
+        const int64_t patch = bid >> 5, within = bid & 31;
+        const int64_t patches_m = tiles_m >> 2;
+        tm = (patch % patches_m) * 4 + (within & 3);
+        tn = (patch / patches_m) * 8 + (within >> 2);
+    } else {
+        tm = bid % tiles_m;
+        tn = bid / tiles_m;
+    }
+    const int64_t m0 = tm << 8, n0 = tn << 8;
+
+    fill_code_lut_rt(s_lut, tid, wp.qt);
+
+    const T *a_src[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int row = 8 * (wave * 4 + i) + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        int64_t m = m0 + row;
+        m = m < M ? m : M - 1;
+        a_src[i] = X + m * K + 8 * c;
+    }
+    auto issue_a = [&](int stage, int64_t k0, int first = 0, int count = 4) {
+#pragma unroll
+        for (int i = first; i < first + count; i++) {
+            auto g = (const __attribute__((address_space(1))) void *)(a_src[i] + k0);
+            auto l = (__attribute__((address_space(3))) void *)(smem + P_A + stage * P_IMG + (wave * 4 + i) * 1024);
+            __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
+        }
+    };
+
+    const int l32 = lane & 31;
+    const int b_row = 32 * wave + 16 * (lane >> 5) + 2 * (l32 & 7) + ((l32 >> 3) & 1);
+    const int b_half = l32 >> 4;
+    int64_t bn = n0 + b_row;
+    bn = bn < N ? bn : N - 1;
+    const uint8_t *p_src = wp.packed + ((bn * wp.K_weight) >> 1) + 16 * b_half;
+    const int64_t am_row = bn * wp.nblk;
+    const int raw_lane = P_RAW + wave * 1024 + lane * 16;
+    const int raw_am = P_RAW + 8192 + wave * 256 + lane * 4;
+    const int raw_am2 = P_RAW + 8192 + 2048 + wave * 256 + lane * 4;
+    auto issue_raw = [&](int rs, int64_t k0) {
+        char *base = smem + P_RAW + rs * RAW_BYTES;
+        {
+            auto g = (const __attribute__((address_space(1))) void *)(p_src + (k0 >> 1));
+            auto l = (__attribute__((address_space(3))) void *)(base + wave * 1024);
+            __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
+        }
+        const int64_t ai = am_row + ((k0 + 32 * b_half) >> wp.bs_shift);
+        if constexpr (!NESTED) {
+            auto g = (const __attribute__((address_space(1))) void *)(wp.am.f32 + ai);
+            auto l = (__attribute__((address_space(3))) void *)(base + 8192 + wave * 256);
+            __builtin_amdgcn_global_load_lds(g, l, 4, 0, 0);
+        } else {
+            auto g = (const __attribute__((address_space(1))) void *)(wp.am.i8 + (ai & ~(int64_t)3));
+            auto l = (__attribute__((address_space(3))) void *)(base + 8192 + wave * 256);
+            __builtin_amdgcn_global_load_lds(g, l, 4, 0, 0);
+            auto g2 = (const __attribute__((address_space(1))) void *)(wp.am.am2 + (ai >> wp.bs2_shift));
+            auto l2 = (__attribute__((address_space(3))) void *)(base + 8192 + 2048 + wave * 256);
+            __builtin_amdgcn_global_load_lds(g2, l2, 4, 0, 0);
+        }
+    };
+    u32x4 rw;
+    float ram;
+    auto load_raw = [&](int rs, int64_t k0) {
+        const char *base = smem + rs * RAW_BYTES;
+        rw = *reinterpret_cast<const u32x4 *>(base + raw_lane);
+        if constexpr (!NESTED) {
+            ram = *reinterpret_cast<const float *>(base + raw_am);
+        } else {
+            const int64_t ai = am_row + ((k0 + 32 * b_half) >> wp.bs_shift);
+            const uint32_t word = *reinterpret_cast<const uint32_t *>(base + raw_am);
+            const float q = (float)(int)(int8_t)(word >> (8 * (int)(ai & 3)));
+            const float a2 = *reinterpret_cast<const float *>(base + raw_am2);
+            ram = q * (a2 / 127.0f);
+        }
+    };
+    int bw_off[4];
+#pragma unroll
+    for (int d = 0; d < 4; d++) bw_off[d] = P_B + swz_off(b_row, 4 * b_half + d);
+    auto emit_q = [&](int d, int stage) {
+        const uint32_t w = rw[d];
+        const uint32_t wo = w & 0xF0F0F0F0u;
+        const uint32_t we = (w << 2) & 0x3C3C3C3Cu;
+        const char *lutb = reinterpret_cast<const char *>(s_lut);
+        u32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t ie = bfe_u32(we, 8 * j, 8);
+            const uint32_t io = bfe_u32(wo, 8 * j + 2, 6);
+            const float lo = *reinterpret_cast<const float *>(lutb + ie) * ram;
+            const float hi = *reinterpret_cast<const float *>(lutb + io) * ram;
+            o[j] = pack2<T>(lo, hi);
+        }
+        *reinterpret_cast<u32x4 *>(smem + stage * P_IMG + bw_off[d]) = o;
+    };
+
+    const int fr = lane & 31, fh = lane >> 5;
+    int fw[4], fx[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        const int f = fr * ROW_BYTES + (((2 * s + fh) ^ ((fr >> 1) & 7)) << 4);
+        fw[s] = P_B + wn * 128 * ROW_BYTES + f;
+        fx[s] = P_A + wm * 64 * ROW_BYTES + f;
+    }
+    Frag wf[2][4], xf[2][2];  // fragments of two k16 groups (one half of a k-step)
+    auto read_half = [&](int stage, int half) {
+#pragma unroll
+        for (int g = 0; g < 2; g++) {
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                wf[g][i] = *reinterpret_cast<const Frag *>(smem + fw[2 * half + g] + stage * P_IMG + i * 32 * ROW_BYTES);
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+                xf[g][j] = *reinterpret_cast<const Frag *>(smem + fx[2 * half + g] + stage * P_IMG + j * 32 * ROW_BYTES);
+        }
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
+    auto mfma_half = [&]() {
+#pragma unroll
+        for (int g = 0; g < 2; g++)
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) acc[i][j] = Mfma<T>::run(wf[g][i], xf[g][j], acc[i][j]);
+    };
+    // 16 MFMAs with two LDS-DMA issue points inside (after the 8th and the 12th MFMA): the DMA
+    // instructions queue behind the CU's L2->LDS path, so they are spread over the matrix segments
+    // where the issuing wave has idle issue slots, instead of bursting after a barrier.
+    auto mfma_half_dma = [&](auto &&dma0, auto &&dma1) {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) acc[i][j] = Mfma<T>::run(wf[0][i], xf[0][j], acc[i][j]);
+        __builtin_amdgcn_sched_barrier(0);
+        dma0();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) acc[i][j] = Mfma<T>::run(wf[1][i], xf[1][j], acc[i][j]);
+        __builtin_amdgcn_sched_barrier(0);
+        dma1();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 2; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) acc[i][j] = Mfma<T>::run(wf[1][i], xf[1][j], acc[i][j]);
+    };
+    int dbg_n = 0;
+    auto stamp = [&]() {
+#ifdef MBNB_ABLATION
+        if constexpr (ablate & 512) {
+            __builtin_amdgcn_sched_barrier(0);
+            unsigned long long t;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+            if (blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0 && dbg_n < 1024) g_dbg_stamps[wave >> 2][dbg_n] = t;
+            dbg_n++;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
+    };
+    auto slot_end = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        stamp();  // work of this slot done
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        stamp();  // next slot starts
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    const int64_t nk = K >> 6;
+    const int64_t k_last = (nk - 1) << 6;
+    auto kclamp = [&](int64_t t) { return t < nk ? t << 6 : k_last; };
+
+    // ---- prologue (all waves together): tile 0 complete in stage 0; quarters 0,1 of tile 1 in stage 1;
+    //      A(1), raw(2) in flight; raw(1) in registers; fragments of tile 0, groups 0,1 in registers
+    issue_a(0, 0);
+    issue_raw(0, 0);
+    issue_raw(1, kclamp(1));
+    MBNB_VMCNT(0);
+    __syncthreads();
+    load_raw(0, 0);
+#pragma unroll
+    for (int d = 0; d < 4; d++) emit_q(d, 0);
+    load_raw(1, kclamp(1));
+    emit_q(0, 1);
+    emit_q(1, 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    issue_a(1, kclamp(1));
+    issue_raw(0, kclamp(2));
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    read_half(0, 0);
+    if (delayed) slot_end();  // waves 4-7 start one slot later
+
+    // LDS-DMA issue plan per wave and k-step j (program order):
+    //   S3(j-1): A(j+1) pieces 0,1 | S0(j): A(j+1) pieces 2,3 | S2(j): raw(j+3) | S3(j): A(j+2) pieces 0,1
+    // The only wait is vmcnt(0) at the end of S1(j): by then everything up to A(j+1) piece 3 has had at
+    // least one full slot to land (raw(j+2), issued in S2(j-1), three slots).
+    auto kstep = [&](auto cc, int64_t j) {
+        constexpr int C = decltype(cc)::value, Nn = C ^ 1;
+        // S0: matrix segment, groups 0,1 (+ second half of A(j+1) -> stage Nn)
+        if constexpr (ablate & 128) __builtin_amdgcn_s_setprio(0);
+        if constexpr (ablate & 256) __builtin_amdgcn_s_setprio(1);
+        if constexpr (!(ablate & 8)) {
+            mfma_half_dma([&] { if constexpr (!(ablate & 1)) { if (j > 0) issue_a(Nn, kclamp(j + 1), 2, 1); } },
+                          [&] { if constexpr (!(ablate & 1)) { if (j > 0) issue_a(Nn, kclamp(j + 1), 3, 1); } });
+        } else {
+            if constexpr (!(ablate & 1)) { if (j > 0) issue_a(Nn, kclamp(j + 1), 2, 2); }
+        }
+        slot_end();
+        // S1: memory segment
+        if constexpr (ablate & 128) __builtin_amdgcn_s_setprio(1);
+        if constexpr (ablate & 256) __builtin_amdgcn_s_setprio(0);
+        if constexpr (!(ablate & 16)) read_half(C, 1);
+        if constexpr (!(ablate & 4)) { emit_q(2, Nn); emit_q(3, Nn); }
+        MBNB_VMCNT(0);  // A(j+1) (this wave's pieces) and raw(j+2) have landed
+        slot_end();
+        // S2: matrix segment, groups 2,3 (+ raw(j+3) -> raw slot Nn)
+        if constexpr (ablate & 128) __builtin_amdgcn_s_setprio(0);
+        if constexpr (ablate & 256) __builtin_amdgcn_s_setprio(1);
+        if constexpr (!(ablate & 8)) {
+            mfma_half_dma([&] { if constexpr (!(ablate & 2)) issue_raw(Nn, kclamp(j + 3)); }, [] {});
+        } else {
+            if constexpr (!(ablate & 2)) issue_raw(Nn, kclamp(j + 3));
+        }
+        slot_end();
+        // S3: memory segment (+ first half of A(j+2) -> stage C, free since both sets passed their S1)
+        if constexpr (ablate & 128) __builtin_amdgcn_s_setprio(1);
+        if constexpr (ablate & 256) __builtin_amdgcn_s_setprio(0);
+        load_raw(C, kclamp(j + 2));
+        if constexpr (!(ablate & 16)) read_half(Nn, 0);
+        if constexpr (!(ablate & 4)) { emit_q(0, C); emit_q(1, C); }
+        if constexpr (!(ablate & 1)) issue_a(C, kclamp(j + 2), 0, 2);
+        slot_end();
+    };
+    for (int64_t j = 0; j < nk; j += 2) {
+        kstep(std::integral_constant<int, 0>{}, j);
+        if (j + 1 < nk) kstep(std::integral_constant<int, 1>{}, j + 1);
+    }
+    if (!delayed) slot_end();
+    MBNB_VMCNT(0);
+
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int64_t m = m0 + wm * 64 + j * 32 + fr;
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int64_t nn = n0 + wn * 128 + i * 32 + 8 * g + 4 * fh;
+                if (m >= M || nn >= N) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    float s = acc[i][j][4 * g + e];
+                    if (bias != nullptr && nn + e < N) s += to_f32(bias[nn + e]);
+                    v[e] = to_f32(from_f32<T>(s));
+                }
+                if (out_dtype == MBNB_F16) store4(static_cast<f16_t *>(out_v) + m * N + nn, v, nn, N);
+                else if (out_dtype == MBNB_BF16) store4(static_cast<bf16_t *>(out_v) + m * N + nn, v, nn, N);
+                else store4(static_cast<float *>(out_v) + m * N + nn, v, nn, N);
+            }
+        }
+}
+
+template <bool NESTED> constexpr int gemm256p_lds_bytes() {
+    return P_RAW + 2 * (8192 + 2048 + (NESTED ? 2048 : 0));
 }
 
 }  // namespace mbnb

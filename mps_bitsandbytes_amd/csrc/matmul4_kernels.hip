@@ -11,6 +11,7 @@
 // Numerics follow the reference CPU branch (functional.py:752-773): the decoded weight is
 // rounded to the weight dtype before the contraction, accumulation is f32, one rounding of the
 // result to the weight dtype, then a cast to the requested output dtype.
+#include <cstdlib>
 #include <type_traits>
 
 #include "gemm256.h"
@@ -221,7 +222,40 @@ static int launch_matmul4(const void *A, int64_t M, int64_t K, const uint8_t *pa
         if (fast_layout && (K % 64 == 0) && ((M + 255) / 256) * ((N + 255) / 256) >= 96) {
             // large problems: 256 x 256 tiles, one workgroup per CU
             using P = Q4ProducerRT<T, NESTED>;
-            typename P::Params wp{packed, am, N, K_weight, K_weight / blocksize, ilog2(blocksize), QT};
+            const bool bs2_pow2 = !NESTED || (am.bs2 > 0 && (am.bs2 & (am.bs2 - 1)) == 0);
+            typename P::Params wp{packed, am, N, K_weight, K_weight / blocksize, ilog2(blocksize), QT,
+                                  NESTED ? ilog2(am.bs2) : 0};
+            const int64_t tiles = ((M + 255) / 256) * ((N + 255) / 256);
+            int od = sizeof(OutT) == 4 ? MBNB_F32 : (std::is_same<OutT, f16_t>::value ? MBNB_F16 : MBNB_BF16);
+            if (bs2_pow2) {
+                static const bool use_pp = getenv("MBNB_PINGPONG") != nullptr;  // debug A/B switch (default: lockstep schedule, faster as measured)
+                using KernT = void (*)(const T *, typename P::Params, const T *, void *, int, int64_t, int64_t, int64_t);
+                KernT kern = use_pp ? k_gemm256pp<T, NESTED> : k_gemm256p<T, NESTED>;
+#ifdef MBNB_ABLATION
+                if constexpr (std::is_same<T, bf16_t>::value && !NESTED) {
+                    static const int abl = getenv("MBNB_ABLATE") ? atoi(getenv("MBNB_ABLATE")) : 0;
+                    switch (abl) {
+#define MBNB_ABL(v) case v: kern = use_pp ? k_gemm256pp<T, NESTED, v> : k_gemm256p<T, NESTED, v>; break;
+                        MBNB_ABL(1) MBNB_ABL(2) MBNB_ABL(3) MBNB_ABL(4) MBNB_ABL(8) MBNB_ABL(16) MBNB_ABL(12) MBNB_ABL(20)
+                        MBNB_ABL(24) MBNB_ABL(28) MBNB_ABL(31) MBNB_ABL(7) MBNB_ABL(23) MBNB_ABL(32) MBNB_ABL(64) MBNB_ABL(128) MBNB_ABL(256) MBNB_ABL(512) MBNB_ABL(520) MBNB_ABL(535) MBNB_ABL(1024)
+#undef MBNB_ABL
+                        default: break;
+                    }
+                }
+#endif
+                constexpr int lds = gemm256p_lds_bytes<NESTED>();
+                {
+                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                    if (e != hipSuccess) {
+                        set_error("matmul_4bit: hipFuncSetAttribute(256p) failed: %s", hipGetErrorString(e));
+                        return (int)e;
+                    }
+                }
+                hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(512), lds, st, x, wp, b, static_cast<void *>(o), od, M, N, K);
+                set_kernel_name("mfma256");
+                return check_launch("matmul_4bit(mfma256)");
+            }
             auto kern = k_gemm256<T, P>;
             static bool attr_done256 = false;
             if (!attr_done256) {
@@ -233,8 +267,6 @@ static int launch_matmul4(const void *A, int64_t M, int64_t K, const uint8_t *pa
                 }
                 attr_done256 = true;
             }
-            const int64_t tiles = ((M + 255) / 256) * ((N + 255) / 256);
-            int od = sizeof(OutT) == 4 ? MBNB_F32 : (std::is_same<OutT, f16_t>::value ? MBNB_F16 : MBNB_BF16);
             hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(512), G256_LDS, st, x, wp, b, static_cast<void *>(o), od, M, N, K);
             set_kernel_name("mfma256");
             return check_launch("matmul_4bit(mfma256)");
@@ -295,6 +327,12 @@ static int matmul4_out(const void *A, int64_t M, int64_t K, const uint8_t *packe
         default: return matmul4_qt<T, float>(A, M, K, packed, am, N, K_weight, blocksize, qt, bias, out, st);
     }
 }
+
+#ifdef MBNB_ABLATION
+extern "C" int mbnb_debug_read_stamps(unsigned long long *host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_dbg_stamps), sizeof(unsigned long long) * 2 * 1024);
+}
+#endif
 
 int matmul_4bit_dispatch(const void *A, int64_t M, int64_t K, const uint8_t *packed, const AbsmaxView &am, int64_t N,
                          int64_t K_weight, int blocksize, int qt, int w_dtype, const void *bias, int out_dtype,

@@ -194,7 +194,7 @@ def test_matmul_k_padded_fast_path():
     assert _oracle_vs_gpu_matmul(1, 64, 96, torch.float16, seed=50) == "gemv"      # K_weight = 128
     assert _oracle_vs_gpu_matmul(2, 64, 4160, torch.float16, seed=52) == "gemv"    # ragged last k-step
     assert _oracle_vs_gpu_matmul(5, 64, 2080, torch.bfloat16, seed=53) == "gemv"
-    assert _oracle_vs_gpu_matmul(1, 64, 72, torch.float16, seed=54) == "generic"   # K % 32 != 0
+    assert _oracle_vs_gpu_matmul(1, 64, 72, torch.float16, seed=54) == "mfma128"   # K % 32 != 0: not the gemv
     assert "mfma" in _oracle_vs_gpu_matmul(64, 128, 200, torch.bfloat16, seed=51)
 
 
