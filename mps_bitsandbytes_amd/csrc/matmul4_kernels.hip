@@ -93,11 +93,15 @@ template <> struct Dot2<bf16_t> {
 // KU k-steps of 2048 (64 lanes x 32 k) are processed per loop trip with ALL their loads issued
 // before the first use; out-of-range chunks load from a clamped address with a zeroed absmax
 // (no branch or select between a load and its use: that makes hipcc wait vmcnt(0) per load).
-template <typename T, typename OutT, int QT, bool NESTED, int MT, int NR, int KU>
+template <typename T, typename OutT, int QT, bool NESTED, int MT, int NR, int KU, bool XLDS>
 __global__ __launch_bounds__(256) void k_gemv4(const T *__restrict__ X, const uint8_t *__restrict__ packed, AbsmaxView am,
                                               const T *__restrict__ bias, OutT *__restrict__ out, int64_t M, int64_t N,
                                               int64_t K, int64_t K_weight, int bs_shift) {
     __shared__ float lut[16];
+    // XLDS: the MT activation rows are staged once per workgroup in LDS (MT*K*2 bytes) and shared by
+    // its 4 waves; otherwise every wave re-reads them from L2, which at M = 1 doubles the bytes moved
+    // through the CU's vector-memory path (the real bound of this kernel, not HBM)
+    extern __shared__ __attribute__((aligned(16))) char xs[];
     const int lane = threadIdx.x & 63;
     const int64_t n0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * NR;
     const int64_t m0 = (int64_t)blockIdx.y * MT;
@@ -123,6 +127,12 @@ __global__ __launch_bounds__(256) void k_gemv4(const T *__restrict__ X, const ui
     for (int i = 0; i < MT; i++) xrow[i] = X + ((m0 + i < M) ? m0 + i : M - 1) * K;
 
     fill_code_lut<QT>(lut, threadIdx.x);
+    if constexpr (XLDS) {
+#pragma unroll
+        for (int i = 0; i < MT; i++)
+            for (int64_t k = (int64_t)threadIdx.x * 8; k < K; k += 256 * 8)
+                *reinterpret_cast<u32x4 *>(xs + (i * K + k) * 2) = *reinterpret_cast<const u32x4 *>(xrow[i] + k);
+    }
     __syncthreads();
     for (int64_t kbase = 0; kbase < K; kbase += 2048 * KU) {
         u32x4 wq[KU][NR];
@@ -146,7 +156,10 @@ __global__ __launch_bounds__(256) void k_gemv4(const T *__restrict__ X, const ui
 #pragma unroll
             for (int c = 0; c < 4; c++)
 #pragma unroll
-                for (int i = 0; i < MT; i++) xv[u][i][c] = *reinterpret_cast<const u32x4 *>(xrow[i] + kc + 8 * c);
+                for (int i = 0; i < MT; i++) {
+                    if constexpr (XLDS) xv[u][i][c] = *reinterpret_cast<const u32x4 *>(xs + (i * K + kc + 8 * c) * 2);
+                    else xv[u][i][c] = *reinterpret_cast<const u32x4 *>(xrow[i] + kc + 8 * c);
+                }
         }
         // keep every load above issued before anything waits on one of them
         __builtin_amdgcn_sched_barrier(0);
@@ -161,10 +174,14 @@ __global__ __launch_bounds__(256) void k_gemv4(const T *__restrict__ X, const ui
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
                     const uint32_t w = wq[u][r][c];
+                    // byte offsets 4*idx into the code table with one v_bfe_u32 per nibble (see gemm256.h)
+                    const uint32_t wo = w & 0xF0F0F0F0u;
+                    const uint32_t we = (w << 2) & 0x3C3C3C3Cu;
+                    const char *lutb = reinterpret_cast<const char *>(lut);
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
-                        const float lo = lut[(w >> (8 * j)) & 15] * a[u][r];
-                        const float hi = lut[(w >> (8 * j + 4)) & 15] * a[u][r];
+                        const float lo = *reinterpret_cast<const float *>(lutb + bfe_u32(we, 8 * j, 8)) * a[u][r];
+                        const float hi = *reinterpret_cast<const float *>(lutb + bfe_u32(wo, 8 * j + 2, 6)) * a[u][r];
                         const uint32_t wp = pack2<T>(lo, hi);
 #pragma unroll
                         for (int i = 0; i < MT; i++) acc[r][i] = Dot2<T>::run(wp, xv[u][i][c][j], acc[r][i]);
@@ -207,12 +224,19 @@ static int launch_matmul4(const void *A, int64_t M, int64_t K, const uint8_t *pa
     if constexpr (is16) {
         if (fast_layout && M <= 16 && (K % 32 == 0)) {
             const int sh = ilog2(blocksize);
+            const bool xlds = (int64_t)8 * K * 2 <= 65536;  // largest MT rows fit the default dynamic-LDS limit
 #define MBNB_GEMV(MT, NR, KU)                                                                                       \
-    hipLaunchKernelGGL((k_gemv4<T, OutT, QT, NESTED, MT, NR, KU>),                                                   \
-                       dim3((unsigned)((N + 4 * NR - 1) / (4 * NR)), (unsigned)((M + MT - 1) / MT)), dim3(256), 0, st, x, \
-                       packed, am, b, o, M, N, K, K_weight, sh)
-            if (M == 1) MBNB_GEMV(1, 2, 2);
-            else if (M == 2) MBNB_GEMV(2, 2, 2);
+    do {                                                                                                            \
+        dim3 grid((unsigned)((N + 4 * NR - 1) / (4 * NR)), (unsigned)((M + MT - 1) / MT));                          \
+        if (xlds)                                                                                                   \
+            hipLaunchKernelGGL((k_gemv4<T, OutT, QT, NESTED, MT, NR, KU, true>), grid, dim3(256), (size_t)MT * K * 2, st, \
+                               x, packed, am, b, o, M, N, K, K_weight, sh);                                         \
+        else                                                                                                        \
+            hipLaunchKernelGGL((k_gemv4<T, OutT, QT, NESTED, MT, NR, KU, false>), grid, dim3(256), 0, st, x, packed, \
+                               am, b, o, M, N, K, K_weight, sh);                                                    \
+    } while (0)
+            if (M == 1) MBNB_GEMV(1, 1, 2);
+            else if (M == 2) MBNB_GEMV(2, 1, 2);
             else if (M <= 4) MBNB_GEMV(4, 2, 1);
             else MBNB_GEMV(8, 1, 1);
 #undef MBNB_GEMV
@@ -237,7 +261,7 @@ static int launch_matmul4(const void *A, int64_t M, int64_t K, const uint8_t *pa
                     switch (abl) {
 #define MBNB_ABL(v) case v: kern = use_pp ? k_gemm256pp<T, NESTED, v> : k_gemm256p<T, NESTED, v>; break;
                         MBNB_ABL(1) MBNB_ABL(2) MBNB_ABL(3) MBNB_ABL(4) MBNB_ABL(8) MBNB_ABL(16) MBNB_ABL(12) MBNB_ABL(20)
-                        MBNB_ABL(24) MBNB_ABL(28) MBNB_ABL(31) MBNB_ABL(7) MBNB_ABL(23) MBNB_ABL(32) MBNB_ABL(64) MBNB_ABL(128) MBNB_ABL(256) MBNB_ABL(512) MBNB_ABL(520) MBNB_ABL(535) MBNB_ABL(1024)
+                        MBNB_ABL(24) MBNB_ABL(28) MBNB_ABL(31) MBNB_ABL(7) MBNB_ABL(23) MBNB_ABL(32) MBNB_ABL(64) MBNB_ABL(128) MBNB_ABL(256) MBNB_ABL(512) MBNB_ABL(520) MBNB_ABL(535) MBNB_ABL(1024) MBNB_ABL(516) MBNB_ABL(515) MBNB_ABL(528) MBNB_ABL(532) MBNB_ABL(519)
 #undef MBNB_ABL
                         default: break;
                     }
