@@ -39,8 +39,8 @@ PEAK_HBM_GBS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="nf4_m4096",
                     choices=["nf4_m4096", "nf4dq_ffn", "int8_4096", "nf4_m1"],
                     help="nf4_m4096 = the BASELINE metric (default); the others are BASELINE configs 3, 4 and 2")
@@ -64,31 +64,25 @@ def event_time_ms(fn, steps):
 
 
 def cpu_baseline(args, M, N, K, blocksize, compress, dtype):
-    """The oracle's matmul_4bit (dequantize -> f32-accumulate GEMM, the reference's CPU algorithm)
-    on the host cores, on the first rows of the same workload; rows chosen for ~cpu_seconds."""
+    """The oracle's matmul_4bit (dequantize -> f32-accumulate GEMM: the reference's CPU algorithm,
+    functional.py:752-773) on this box's host cores.  Sample: the same [M, K] x [N, K]^T workload
+    (same synthetic weight), repeated until ~cpu_seconds of CPU time have been spent."""
     import oracle
     from mps_bitsandbytes_amd import synthetic
     threads = oracle.num_threads()
     W = synthetic.normal((N, K), dtype, seed=1234)
     packed, absmax, st2 = oracle.quantize_4bit(W, blocksize, "nf4", compress)
-    X = synthetic.normal((256, K), dtype, seed=4321)
-    t0 = time.perf_counter()
-    oracle.matmul_4bit(X[:32], packed, absmax, (N, K), blocksize, "nf4", dtype, None, None, st2)
-    t_small = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    oracle.matmul_4bit(X, packed, absmax, (N, K), blocksize, "nf4", dtype, None, None, st2)
-    t_256 = time.perf_counter() - t0
-    per_row = max((t_256 - t_small) / (256 - 32), 1e-6)
-    fixed = max(t_small - 32 * per_row, 0.0)
-    rows = int(max(256, min(M, (args.cpu_seconds - fixed) / per_row)))
-    rows = (rows // 64) * 64
-    Xs = synthetic.normal((rows, K), dtype, seed=4321)
-    t0 = time.perf_counter()
-    oracle.matmul_4bit(Xs, packed, absmax, (N, K), blocksize, "nf4", dtype, None, None, st2)
-    dt = time.perf_counter() - t0
-    return {"value": round(2.0 * rows * N * K / dt / 1e12, 5), "unit": "TFLOP/s", "cores": threads, "kind": "port",
-            "sample": f"first {rows} of {M} rows of the same batch (full {N}x{K} weight dequantized once), "
-                      f"{dt:.1f} s, OpenMP {threads} threads, host has {os.cpu_count()} logical cpus"}
+    X = synthetic.normal((M, K), dtype, seed=4321)
+    oracle.matmul_4bit(X[:64], packed, absmax, (N, K), blocksize, "nf4", dtype, None, None, st2)  # warm the pool
+    reps, spent = 0, 0.0
+    while spent < args.cpu_seconds and reps < 64:
+        t0 = time.perf_counter()
+        oracle.matmul_4bit(X, packed, absmax, (N, K), blocksize, "nf4", dtype, None, None, st2)
+        spent += time.perf_counter() - t0
+        reps += 1
+    return {"value": round(2.0 * M * N * K * reps / spent / 1e12, 5), "unit": "TFLOP/s", "cores": threads, "kind": "port",
+            "sample": f"{reps} x the full step (M={M} rows, {N}x{K} weight dequantized per call), {spent:.1f} s of CPU time, "
+                      f"OpenMP {threads} threads on {os.cpu_count()} logical cpus; C port of the reference's CPU path (oracle/)"}
 
 
 def main():
@@ -276,7 +270,7 @@ def main():
         prof = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(prof):
             try:
-                out["roofline"]["traffic"] = json.load(open(prof)).get("k_gemm_decode_bytes_per_launch")
+                out["roofline"]["traffic"] = json.load(open(prof)).get("k_gemm256p_bytes_per_launch")
             except Exception:
                 pass
     if distributed:
