@@ -43,6 +43,8 @@ template <typename T, bool NESTED> struct Q4ProducerRT {
         int bs_shift;
         int qt;
         int bs2_shift;  // log2(absmax blocksize2) for the nested form (k_gemm256p only)
+        int w8, w6;     // the constants 8 and 6, passed at run time so hipcc keeps v_bfe_u32 (it folds a
+                        // constant-width field extract into shift + and, one VALU instruction more)
     };
     struct Regs {
         u32x4 w;
@@ -350,9 +352,9 @@ __global__ __launch_bounds__(512, 2) void k_gemm256p(const T *__restrict__ X, ty
         m = m < M ? m : M - 1;
         a_src[i] = X + m * K + 8 * c;
     }
-    auto issue_a = [&](int stage, int64_t k0) {
+    auto issue_a = [&](int stage, int64_t k0, int first = 0, int count = 4) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
+        for (int i = first; i < first + count; i++) {
             auto g = (const __attribute__((address_space(1))) void *)(a_src[i] + k0);
             auto l = (__attribute__((address_space(3))) void *)(smem + P_A + stage * P_IMG + (wave * 4 + i) * 1024);
             __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
@@ -394,42 +396,103 @@ __global__ __launch_bounds__(512, 2) void k_gemm256p(const T *__restrict__ X, ty
             __builtin_amdgcn_global_load_lds(g2, l2, 4, 0, 0);
         }
     };
-    u32x4 rw;
-    float ram;
-    auto load_raw = [&](int rs, int64_t k0) {
+    // raw registers of the tile being decoded, by tile parity
+    u32x4 rw[2];
+    float ram[2];
+    auto load_raw = [&](auto pp, int rs, int64_t k0) {
+        constexpr int P = decltype(pp)::value;
         const char *base = smem + rs * RAW_BYTES;
-        rw = *reinterpret_cast<const u32x4 *>(base + raw_lane);
+        rw[P] = *reinterpret_cast<const u32x4 *>(base + raw_lane);
         if constexpr (!NESTED) {
-            ram = *reinterpret_cast<const float *>(base + raw_am);
+            ram[P] = *reinterpret_cast<const float *>(base + raw_am);
         } else {
             const int64_t ai = am_row + ((k0 + 32 * b_half) >> wp.bs_shift);
             const uint32_t word = *reinterpret_cast<const uint32_t *>(base + raw_am);
             const float q = (float)(int)(int8_t)(word >> (8 * (int)(ai & 3)));
             const float a2 = *reinterpret_cast<const float *>(base + raw_am2);
-            ram = q * (a2 / 127.0f);  // dequantize_blockwise arithmetic (functional.py:592-594)
+            ram[P] = q * (a2 / 127.0f);  // dequantize_blockwise arithmetic (functional.py:592-594)
         }
     };
     int bw_off[4];  // byte offsets of this thread's 4 output chunks inside stage 0 of the B image
 #pragma unroll
     for (int d = 0; d < 4; d++) bw_off[d] = P_B + swz_off(b_row, 4 * b_half + d);
-    // decode quarter d (8 k) of the raw registers into B image `stage`
-    auto emit_q = [&](int d, int stage) {
-        const uint32_t w = rw[d];
-        // byte offsets (4 * idx) into the code table: odd nibbles sit at bits 8j+4..8j+7, so a 6-bit
-        // field at 8j+2 of (w & 0xF0F0F0F0) is idx*4; even nibbles after (w << 2) & 0x3C3C3C3C.
+    // decode of a quarter (8 k) is split in two halves issued one MFMA group apart, so the table
+    // lookups' LDS latency is covered by 8 MFMAs instead of being waited for in place:
+    //   lookup_q: byte offsets 4*idx with one v_bfe_u32 per nibble (odd nibbles: 6-bit field at 8j+2 of
+    //             w & 0xF0F0F0F0; even: byte j of (w << 2) & 0x3C3C3C3C), then 8 ds_read_b32
+    //   finish_q: value = code * absmax in f32 -> RNE 16-bit (the reference's dequantize_4bit bits) -> ds_write_b128
+    auto lookup_q = [&](uint32_t w, float (&L)[8]) {
         const uint32_t wo = w & 0xF0F0F0F0u;
         const uint32_t we = (w << 2) & 0x3C3C3C3Cu;
         const char *lutb = reinterpret_cast<const char *>(s_lut);
-        u32x4 o;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const uint32_t ie = bfe_u32(we, 8 * j, 8);
-            const uint32_t io = bfe_u32(wo, 8 * j + 2, 6);
-            const float lo = *reinterpret_cast<const float *>(lutb + ie) * ram;
-            const float hi = *reinterpret_cast<const float *>(lutb + io) * ram;
-            o[j] = pack2<T>(lo, hi);
+            L[2 * j] = *reinterpret_cast<const float *>(lutb + __builtin_amdgcn_ubfe(we, 8 * j, wp.w8));
+            L[2 * j + 1] = *reinterpret_cast<const float *>(lutb + __builtin_amdgcn_ubfe(wo, 8 * j + 2, wp.w6));
         }
+    };
+    auto finish_q = [&](const float (&L)[8], float am, int d, int stage) {
+        u32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; j++) o[j] = pack2<T>(L[2 * j] * am, L[2 * j + 1] * am);
         *reinterpret_cast<u32x4 *>(smem + stage * P_IMG + bw_off[d]) = o;
+    };
+    float La[8], Lb[8], Lc[8];   // looked-up code values in flight: quarters (0 then 2), 1, 3
+    float L01[2][8], L23[2][8];  // (VALU-decode debug variant only)
+    // interleave directive for one MFMA group: per MFMA `nv` VALU and `nr` LDS reads (+ `nw` LDS writes on
+    // the last MFMAs, `nm` LDS-DMA issues in the middle).  Within one wave non-MFMA instructions issue in
+    // the shadow of the wave's own MFMAs only when they sit between them; clustered runs serialise with
+    // the SIMD partner's MFMAs (tools/coexec_probe.hip).
+    auto interleave = [&](auto nv_, auto nr_, auto nw_, auto nm_) {
+        constexpr int nv = decltype(nv_)::value, nr = decltype(nr_)::value, nw = decltype(nw_)::value, nm = decltype(nm_)::value;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (nr > 0) __builtin_amdgcn_sched_group_barrier(0x100, nr, 0);
+            if (nv > 0) __builtin_amdgcn_sched_group_barrier(0x002, nv, 0);
+            if (nm > 0 && r >= 2 && r < 2 + nm) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            if (nw > 0 && r >= 8 - nw) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>;
+    // ---- ablate & 2048: table-free decode on the VALU (no LDS lookups).  Per thread and tile the 16
+    // scaled code values RNE16(code[i] * absmax) are built once (16 v_mul + 8 cvt_pk) and split into
+    // byte planes TL/TH (low / high bytes of entries 4q..4q+3); a nibble is then looked up with
+    // v_perm_b32: entries 0-7 and 8-15 by its low 3 bits, merged by bit 3, planes re-interleaved.
+    uint32_t TL[4], TH[4];
+    auto build_table = [&](float am) {
+        uint32_t Tp[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const float c0 = (wp.qt == MBNB_NF4) ? nf4_code(2 * r) : fp4_code(2 * r);
+            const float c1 = (wp.qt == MBNB_NF4) ? nf4_code(2 * r + 1) : fp4_code(2 * r + 1);
+            Tp[r] = pack2<T>(c0 * am, c1 * am);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            TL[q] = __builtin_amdgcn_perm(Tp[2 * q + 1], Tp[2 * q], 0x06040200u);
+            TH[q] = __builtin_amdgcn_perm(Tp[2 * q + 1], Tp[2 * q], 0x07050301u);
+        }
+    };
+    auto decode_q_valu = [&](uint32_t w, int d, int stage) {
+        const uint32_t o = w >> 4;
+        const uint32_t selLE = w & 0x07070707u, selLO = o & 0x07070707u;
+        const uint32_t sel3E = ((w >> 1) & 0x04040404u) | 0x03020100u;
+        const uint32_t sel3O = ((o >> 1) & 0x04040404u) | 0x03020100u;
+        auto plane = [&](const uint32_t (&P)[4], uint32_t selL, uint32_t sel3) {
+            return __builtin_amdgcn_perm(__builtin_amdgcn_perm(P[3], P[2], selL), __builtin_amdgcn_perm(P[1], P[0], selL), sel3);
+        };
+        const uint32_t LE = plane(TL, selLE, sel3E), HE = plane(TH, selLE, sel3E);
+        const uint32_t LO = plane(TL, selLO, sel3O), HO = plane(TH, selLO, sel3O);
+        const uint32_t E0 = __builtin_amdgcn_perm(HE, LE, 0x05010400u), E1 = __builtin_amdgcn_perm(HE, LE, 0x07030602u);
+        const uint32_t O0 = __builtin_amdgcn_perm(HO, LO, 0x05010400u), O1 = __builtin_amdgcn_perm(HO, LO, 0x07030602u);
+        u32x4 out;
+        out[0] = __builtin_amdgcn_perm(O0, E0, 0x05040100u);
+        out[1] = __builtin_amdgcn_perm(O0, E0, 0x07060302u);
+        out[2] = __builtin_amdgcn_perm(O1, E1, 0x05040100u);
+        out[3] = __builtin_amdgcn_perm(O1, E1, 0x07060302u);
+        *reinterpret_cast<u32x4 *>(smem + stage * P_IMG + bw_off[d]) = out;
     };
 
     // ---- fragment read offsets: per MFMA group s (chunk 2s + fh, swizzled by the row)
@@ -466,15 +529,23 @@ __global__ __launch_bounds__(512, 2) void k_gemm256p(const T *__restrict__ X, ty
     const int64_t k_last = (nk - 1) << 6;
     auto kclamp = [&](int64_t t) { return t < nk ? t << 6 : k_last; };
 
-    // ---- prologue: stage 0 <- tile 0, raw slots <- tiles 0 (then 2) and 1, A(1) in flight
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    // ---- prologue: stage 0 <- tile 0; raw(1) in registers with quarters 0,1 looked up; A(1), raw(2) in flight
     issue_a(0, 0);
     issue_raw(0, 0);
     issue_raw(1, kclamp(1));
     MBNB_VMCNT(0);
     __syncthreads();  // code table, A(0) and this wave's raw(0), raw(1) visible
-    load_raw(0, 0);
+    load_raw(P0{}, 0, 0);
 #pragma unroll
-    for (int d = 0; d < 4; d++) emit_q(d, 0);
+    for (int d = 0; d < 4; d++) {
+        float L[8];
+        lookup_q(rw[0][d], L);
+        finish_q(L, ram[0], d, 0);
+    }
+    load_raw(P1{}, 1, kclamp(1));
+    lookup_q(rw[1][0], La);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     issue_a(1, kclamp(1));
     issue_raw(0, kclamp(2));
@@ -483,53 +554,83 @@ __global__ __launch_bounds__(512, 2) void k_gemm256p(const T *__restrict__ X, ty
     Frag wfA[4], xfA[2], wfB[4], xfB[2];
     read_frags(0, 0, wfA, xfA);
 
-    // one k-step with compile-time stage parity C (stage C holds tile j, stage C^1 receives tile j+1)
+    int dbg_n = 0;
+    auto stamp = [&]() {
+#ifdef MBNB_ABLATION
+        if constexpr (ablate & 512) {
+            __builtin_amdgcn_sched_barrier(0);
+            unsigned long long t;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+            if (blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0 && dbg_n < 1024) g_dbg_stamps[wave >> 2][dbg_n] = t;
+            dbg_n++;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
+    };
+    // one k-step with compile-time stage parity C (stage C holds tile j; tile j+1, parity Nn, is decoded
+    // into stage Nn: its raw registers and quarters 0,1 lookups were issued in group 3 of the previous step)
     auto kstep = [&](auto cc, int64_t j) {
         constexpr int C = decltype(cc)::value, Nn = C ^ 1;
+        using PC = std::integral_constant<int, C>;
+        // Decode pipeline of tile j+1 (raw registers parity Nn), one quarter = 8 k:
+        //   lookup:  q0 @ group 3 of step j-1 | q1 @ group 0 | q2, q3 @ group 1
+        //   finish:  q0 @ group 0            | q1 @ group 1 | q2, q3 @ group 2   (all before barrier j)
         // group 0
-        if constexpr (NESTED) MBNB_VMCNT(7); else MBNB_VMCNT(6);  // 4 + R: this wave's raw(j+1) has landed in slot Nn
-        load_raw(Nn, kclamp(j + 1));
-        if constexpr (!(ablate & 8)) mfma_group(wfA, xfA);
-        if constexpr (!(ablate & 4)) { emit_q(0, Nn); emit_q(1, Nn); }
         if constexpr (!(ablate & 16)) read_frags(C, 1, wfB, xfB);
-        if constexpr (ablate & 1024) {
-#pragma unroll
-            for (int r = 0; r < 8; r++) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
-                if (r >= 6) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // group 1
-        if constexpr (!(ablate & 8)) mfma_group(wfB, xfB);
-        if constexpr (!(ablate & 4)) { emit_q(2, Nn); emit_q(3, Nn); }
-        if constexpr (!(ablate & 16)) read_frags(C, 2, wfA, xfA);
-        if constexpr (ablate & 1024) {
-#pragma unroll
-            for (int r = 0; r < 8; r++) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
-                if (r >= 6) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // group 2
         if constexpr (!(ablate & 8)) mfma_group(wfA, xfA);
+        if constexpr (ablate & 2048) {
+            build_table(ram[Nn]);
+            decode_q_valu(rw[Nn][0], 0, Nn);
+            decode_q_valu(rw[Nn][1], 1, Nn);
+        } else if constexpr (!(ablate & 4)) {
+            finish_q(La, ram[Nn], 0, Nn);
+            lookup_q(rw[Nn][1], Lb);
+        }
+        if constexpr (!(ablate & 1)) { if (j > 0) issue_a(Nn, kclamp(j + 1), 2, 1); }
+        if constexpr (ablate & 4096) interleave(I3{}, I2{}, I1{}, I1{});
+        __builtin_amdgcn_sched_barrier(0);
+        stamp();
+        // group 1
+        if constexpr (!(ablate & 16)) read_frags(C, 2, wfA, xfA);
+        if constexpr (!(ablate & 8)) mfma_group(wfB, xfB);
+        if constexpr (ablate & 2048) {
+            decode_q_valu(rw[Nn][2], 2, Nn);
+            decode_q_valu(rw[Nn][3], 3, Nn);
+        } else if constexpr (!(ablate & 4)) {
+            finish_q(Lb, ram[Nn], 1, Nn);
+            lookup_q(rw[Nn][2], La);
+            lookup_q(rw[Nn][3], Lc);
+        }
+        if constexpr (!(ablate & 1)) { if (j > 0) issue_a(Nn, kclamp(j + 1), 3, 1); }
+        if constexpr (ablate & 4096) interleave(I4{}, I3{}, I1{}, I1{});
+        __builtin_amdgcn_sched_barrier(0);
+        stamp();
+        // group 2
         if constexpr (!(ablate & 16)) read_frags(C, 3, wfB, xfB);
-        if constexpr (NESTED) MBNB_VMCNT(3); else MBNB_VMCNT(2);  // R: A(j+1) landed (this wave's pieces)
+        if constexpr (!(ablate & 8)) mfma_group(wfA, xfA);
+        if constexpr (!(ablate & 4) && !(ablate & 2048)) {
+            finish_q(La, ram[Nn], 2, Nn);
+            finish_q(Lc, ram[Nn], 3, Nn);
+        }
+        if constexpr (!(ablate & 2)) issue_raw(Nn, kclamp(j + 3));
+        if constexpr (ablate & 4096) interleave(I4{}, I1{}, I2{}, I2{});
+        __builtin_amdgcn_sched_barrier(0);
+        stamp();
+        if constexpr (NESTED) MBNB_VMCNT(3); else MBNB_VMCNT(2);  // R: all but raw(j+3): A(j+1) and raw(j+2) landed
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // own decode writes + fragment reads done
         __builtin_amdgcn_s_barrier();                         // stage Nn complete, stage C free
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        // group 3: refill stage C and raw slot Nn; first fragments of stage Nn
-        if constexpr (!(ablate & 8)) mfma_group(wfB, xfB);
-        if constexpr (!(ablate & 1)) issue_a(C, kclamp(j + 2));
-        if constexpr (!(ablate & 2)) issue_raw(Nn, kclamp(j + 3));
+        stamp();
+        // group 3: first fragments of stage Nn; refill stage C; raw(j+2) -> registers; look up its quarter 0
         if constexpr (!(ablate & 16)) read_frags(Nn, 0, wfA, xfA);
+        load_raw(PC{}, C, kclamp(j + 2));  // raw(j+2) landed before the barrier above
+        if constexpr (!(ablate & 8)) mfma_group(wfB, xfB);
+        if constexpr (!(ablate & 4) && !(ablate & 2048)) lookup_q(rw[C][0], La);
+        if constexpr (!(ablate & 1)) issue_a(C, kclamp(j + 2), 0, 2);
+        if constexpr (ablate & 4096) interleave(I2{}, I2{}, I0{}, I2{});
         __builtin_amdgcn_sched_barrier(0);
+        stamp();
     };
     for (int64_t j = 0; j < nk; j += 2) {
         kstep(std::integral_constant<int, 0>{}, j);
@@ -667,40 +768,51 @@ __global__ __launch_bounds__(512, 2) void k_gemm256pp(const T *__restrict__ X, t
             __builtin_amdgcn_global_load_lds(g2, l2, 4, 0, 0);
         }
     };
-    u32x4 rw;
-    float ram;
-    auto load_raw = [&](int rs, int64_t k0) {
+    // raw registers of the tile being decoded, by tile parity (a tile's decode spans two k-steps)
+    u32x4 rw[2];
+    float ram[2];
+    auto load_raw = [&](auto pp, int rs, int64_t k0) {
+        constexpr int P = decltype(pp)::value;
         const char *base = smem + rs * RAW_BYTES;
-        rw = *reinterpret_cast<const u32x4 *>(base + raw_lane);
+        rw[P] = *reinterpret_cast<const u32x4 *>(base + raw_lane);
         if constexpr (!NESTED) {
-            ram = *reinterpret_cast<const float *>(base + raw_am);
+            ram[P] = *reinterpret_cast<const float *>(base + raw_am);
         } else {
             const int64_t ai = am_row + ((k0 + 32 * b_half) >> wp.bs_shift);
             const uint32_t word = *reinterpret_cast<const uint32_t *>(base + raw_am);
             const float q = (float)(int)(int8_t)(word >> (8 * (int)(ai & 3)));
             const float a2 = *reinterpret_cast<const float *>(base + raw_am2);
-            ram = q * (a2 / 127.0f);
+            ram[P] = q * (a2 / 127.0f);
         }
     };
     int bw_off[4];
 #pragma unroll
     for (int d = 0; d < 4; d++) bw_off[d] = P_B + swz_off(b_row, 4 * b_half + d);
-    auto emit_q = [&](int d, int stage) {
-        const uint32_t w = rw[d];
+    // decode, split in two so that the table lookups of a quarter are issued one memory segment
+    // before their products are formed (the lookup latency hides behind the matrix segment in between)
+    auto lookup_q = [&](uint32_t w, float (&L)[8]) {
         const uint32_t wo = w & 0xF0F0F0F0u;
         const uint32_t we = (w << 2) & 0x3C3C3C3Cu;
         const char *lutb = reinterpret_cast<const char *>(s_lut);
-        u32x4 o;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const uint32_t ie = bfe_u32(we, 8 * j, 8);
-            const uint32_t io = bfe_u32(wo, 8 * j + 2, 6);
-            const float lo = *reinterpret_cast<const float *>(lutb + ie) * ram;
-            const float hi = *reinterpret_cast<const float *>(lutb + io) * ram;
-            o[j] = pack2<T>(lo, hi);
+            L[2 * j] = *reinterpret_cast<const float *>(lutb + bfe_u32(we, 8 * j, 8));
+            L[2 * j + 1] = *reinterpret_cast<const float *>(lutb + bfe_u32(wo, 8 * j + 2, 6));
         }
+    };
+    auto finish_q = [&](const float (&L)[8], float am, int d, int stage) {
+        u32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; j++) o[j] = pack2<T>(L[2 * j] * am, L[2 * j + 1] * am);
         *reinterpret_cast<u32x4 *>(smem + stage * P_IMG + bw_off[d]) = o;
     };
+    auto emit_q = [&](auto pp, int d, int stage) {  // unpipelined form (prologue only)
+        constexpr int P = decltype(pp)::value;
+        float L[8];
+        lookup_q(rw[P][d], L);
+        finish_q(L, ram[P], d, stage);
+    };
+    float L01[2][8], L23[2][8];  // looked-up code values of quarters (0,1) and (2,3) in flight
 
     const int fr = lane & 31, fh = lane >> 5;
     int fw[4], fx[4];
@@ -787,19 +899,23 @@ __global__ __launch_bounds__(512, 2) void k_gemm256pp(const T *__restrict__ X, t
     const int64_t k_last = (nk - 1) << 6;
     auto kclamp = [&](int64_t t) { return t < nk ? t << 6 : k_last; };
 
-    // ---- prologue (all waves together): tile 0 complete in stage 0; quarters 0,1 of tile 1 in stage 1;
-    //      A(1), raw(2) in flight; raw(1) in registers; fragments of tile 0, groups 0,1 in registers
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    // ---- prologue (all waves together): tile 0 complete in stage 0; tile 1: quarters 0,1 in stage 1,
+    //      quarters 2,3 looked up; A(1), raw(2) in flight; fragments of tile 0, groups 0,1 in registers
     issue_a(0, 0);
     issue_raw(0, 0);
     issue_raw(1, kclamp(1));
     MBNB_VMCNT(0);
     __syncthreads();
-    load_raw(0, 0);
+    load_raw(P0{}, 0, 0);
 #pragma unroll
-    for (int d = 0; d < 4; d++) emit_q(d, 0);
-    load_raw(1, kclamp(1));
-    emit_q(0, 1);
-    emit_q(1, 1);
+    for (int d = 0; d < 4; d++) emit_q(P0{}, d, 0);
+    load_raw(P1{}, 1, kclamp(1));
+    emit_q(P1{}, 0, 1);
+    emit_q(P1{}, 1, 1);
+    lookup_q(rw[1][2], L23[0]);
+    lookup_q(rw[1][3], L23[1]);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     issue_a(1, kclamp(1));
     issue_raw(0, kclamp(2));
@@ -810,13 +926,12 @@ __global__ __launch_bounds__(512, 2) void k_gemm256pp(const T *__restrict__ X, t
 
     // LDS-DMA issue plan per wave and k-step j (program order):
     //   S3(j-1): A(j+1) pieces 0,1 | S0(j): A(j+1) pieces 2,3 | S2(j): raw(j+3) | S3(j): A(j+2) pieces 0,1
-    // The only wait is vmcnt(0) at the end of S1(j): by then everything up to A(j+1) piece 3 has had at
-    // least one full slot to land (raw(j+2), issued in S2(j-1), three slots).
+    // Decode of tile t (parity t&1) is a 3-slot pipeline:
+    //   S1(t-2): load raw(t), look up quarters 0,1 | S3(t-2): finish 0,1 -> stage t&1, look up 2,3 | S1(t-1): finish 2,3
     auto kstep = [&](auto cc, int64_t j) {
         constexpr int C = decltype(cc)::value, Nn = C ^ 1;
+        using PC = std::integral_constant<int, C>;
         // S0: matrix segment, groups 0,1 (+ second half of A(j+1) -> stage Nn)
-        if constexpr (ablate & 128) __builtin_amdgcn_s_setprio(0);
-        if constexpr (ablate & 256) __builtin_amdgcn_s_setprio(1);
         if constexpr (!(ablate & 8)) {
             mfma_half_dma([&] { if constexpr (!(ablate & 1)) { if (j > 0) issue_a(Nn, kclamp(j + 1), 2, 1); } },
                           [&] { if constexpr (!(ablate & 1)) { if (j > 0) issue_a(Nn, kclamp(j + 1), 3, 1); } });
@@ -824,16 +939,16 @@ __global__ __launch_bounds__(512, 2) void k_gemm256pp(const T *__restrict__ X, t
             if constexpr (!(ablate & 1)) { if (j > 0) issue_a(Nn, kclamp(j + 1), 2, 2); }
         }
         slot_end();
-        // S1: memory segment
-        if constexpr (ablate & 128) __builtin_amdgcn_s_setprio(1);
-        if constexpr (ablate & 256) __builtin_amdgcn_s_setprio(0);
+        // S1: memory segment.  raw(j+2) (tile parity C) was issued at S2(j-1): everything but the four
+        // A(j+1) pieces issued after it has landed after vmcnt(4) (at j = 0 the prologue order differs).
+        if (j == 0) { MBNB_VMCNT(0); } else { MBNB_VMCNT(4); }
+        load_raw(PC{}, C, kclamp(j + 2));
+        if constexpr (!(ablate & 4)) { lookup_q(rw[C][0], L01[0]); lookup_q(rw[C][1], L01[1]); }
+        if constexpr (!(ablate & 4)) { finish_q(L23[0], ram[Nn], 2, Nn); finish_q(L23[1], ram[Nn], 3, Nn); }
         if constexpr (!(ablate & 16)) read_half(C, 1);
-        if constexpr (!(ablate & 4)) { emit_q(2, Nn); emit_q(3, Nn); }
-        MBNB_VMCNT(0);  // A(j+1) (this wave's pieces) and raw(j+2) have landed
+        MBNB_VMCNT(0);  // A(j+1): this wave's pieces have landed
         slot_end();
         // S2: matrix segment, groups 2,3 (+ raw(j+3) -> raw slot Nn)
-        if constexpr (ablate & 128) __builtin_amdgcn_s_setprio(0);
-        if constexpr (ablate & 256) __builtin_amdgcn_s_setprio(1);
         if constexpr (!(ablate & 8)) {
             mfma_half_dma([&] { if constexpr (!(ablate & 2)) issue_raw(Nn, kclamp(j + 3)); }, [] {});
         } else {
@@ -841,11 +956,9 @@ __global__ __launch_bounds__(512, 2) void k_gemm256pp(const T *__restrict__ X, t
         }
         slot_end();
         // S3: memory segment (+ first half of A(j+2) -> stage C, free since both sets passed their S1)
-        if constexpr (ablate & 128) __builtin_amdgcn_s_setprio(1);
-        if constexpr (ablate & 256) __builtin_amdgcn_s_setprio(0);
-        load_raw(C, kclamp(j + 2));
+        if constexpr (!(ablate & 4)) { lookup_q(rw[C][2], L23[0]); lookup_q(rw[C][3], L23[1]); }
+        if constexpr (!(ablate & 4)) { finish_q(L01[0], ram[C], 0, C); finish_q(L01[1], ram[C], 1, C); }
         if constexpr (!(ablate & 16)) read_half(Nn, 0);
-        if constexpr (!(ablate & 4)) { emit_q(0, C); emit_q(1, C); }
         if constexpr (!(ablate & 1)) issue_a(C, kclamp(j + 2), 0, 2);
         slot_end();
     };

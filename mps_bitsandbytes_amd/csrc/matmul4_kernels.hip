@@ -248,7 +248,7 @@ static int launch_matmul4(const void *A, int64_t M, int64_t K, const uint8_t *pa
             using P = Q4ProducerRT<T, NESTED>;
             const bool bs2_pow2 = !NESTED || (am.bs2 > 0 && (am.bs2 & (am.bs2 - 1)) == 0);
             typename P::Params wp{packed, am, N, K_weight, K_weight / blocksize, ilog2(blocksize), QT,
-                                  NESTED ? ilog2(am.bs2) : 0};
+                                  NESTED ? ilog2(am.bs2) : 0, 8, 6};
             const int64_t tiles = ((M + 255) / 256) * ((N + 255) / 256);
             int od = sizeof(OutT) == 4 ? MBNB_F32 : (std::is_same<OutT, f16_t>::value ? MBNB_F16 : MBNB_BF16);
             if (bs2_pow2) {
@@ -261,7 +261,7 @@ static int launch_matmul4(const void *A, int64_t M, int64_t K, const uint8_t *pa
                     switch (abl) {
 #define MBNB_ABL(v) case v: kern = use_pp ? k_gemm256pp<T, NESTED, v> : k_gemm256p<T, NESTED, v>; break;
                         MBNB_ABL(1) MBNB_ABL(2) MBNB_ABL(3) MBNB_ABL(4) MBNB_ABL(8) MBNB_ABL(16) MBNB_ABL(12) MBNB_ABL(20)
-                        MBNB_ABL(24) MBNB_ABL(28) MBNB_ABL(31) MBNB_ABL(7) MBNB_ABL(23) MBNB_ABL(32) MBNB_ABL(64) MBNB_ABL(128) MBNB_ABL(256) MBNB_ABL(512) MBNB_ABL(520) MBNB_ABL(535) MBNB_ABL(1024) MBNB_ABL(516) MBNB_ABL(515) MBNB_ABL(528) MBNB_ABL(532) MBNB_ABL(519)
+                        MBNB_ABL(24) MBNB_ABL(28) MBNB_ABL(31) MBNB_ABL(7) MBNB_ABL(23) MBNB_ABL(32) MBNB_ABL(64) MBNB_ABL(128) MBNB_ABL(256) MBNB_ABL(512) MBNB_ABL(520) MBNB_ABL(535) MBNB_ABL(1024) MBNB_ABL(2048) MBNB_ABL(2056) MBNB_ABL(4096) MBNB_ABL(4608) MBNB_ABL(516) MBNB_ABL(515) MBNB_ABL(528) MBNB_ABL(532) MBNB_ABL(519)
 #undef MBNB_ABL
                         default: break;
                     }
