@@ -254,7 +254,8 @@ static int launch_matmul4(const void *A, int64_t M, int64_t K, const uint8_t *pa
             if (bs2_pow2) {
                 static const bool use_pp = getenv("MBNB_PINGPONG") != nullptr;  // debug A/B switch (default: lockstep schedule, faster as measured)
                 using KernT = void (*)(const T *, typename P::Params, const T *, void *, int, int64_t, int64_t, int64_t);
-                KernT kern = use_pp ? k_gemm256pp<T, NESTED> : k_gemm256p<T, NESTED>;
+                                static const bool use_valu = getenv("MBNB_VALUDEC") != nullptr;  // debug A/B switch: slot-pinned + VALU decode
+                KernT kern = use_valu ? k_gemm256v<T, NESTED> : (use_pp ? k_gemm256pp<T, NESTED> : k_gemm256p<T, NESTED>);
 #ifdef MBNB_ABLATION
                 if constexpr (std::is_same<T, bf16_t>::value && !NESTED) {
                     static const int abl = getenv("MBNB_ABLATE") ? atoi(getenv("MBNB_ABLATE")) : 0;

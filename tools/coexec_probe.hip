@@ -90,6 +90,35 @@ __global__ __launch_bounds__(512, 2) void probe(float *out, int roleA, int roleB
         }
         r = (float)accum;
     }
+    else if (role >= 7 && role <= 10) {
+        // LDS mix of one k-step of k_gemm256p per wave: 24 ds_read_b128 (conflict-free rows), 32 ds_read_b32 from a
+        // 16-entry table, 4 ds_write_b128.  role 7: all three; 8: only the b128 reads; 9: only the table reads; 10: only writes
+        __shared__ __attribute__((aligned(16))) char img[65536];
+        const int lane = threadIdx.x & 63;
+        const int fr = lane & 31, fh = lane >> 5;
+        unsigned faddr = fr * 128 + ((fh ^ ((fr >> 1) & 7)) << 4) + (wave & 1) * 8192;
+        unsigned waddr = (threadIdx.x >> 1) * 128 + (((threadIdx.x & 1) * 4) << 4);
+        unsigned accum = 0; float facc = 0; unsigned idx = threadIdx.x * 7;
+        for (int it = 0; it < n; it++) {
+            if (role == 7 || role == 8) {
+#pragma unroll
+                for (int q = 0; q < 24; q++) {
+                    u32x4 f = *reinterpret_cast<const u32x4 *>(img + ((faddr + (q & 3) * 4096 + (q >> 2) * 32 + (it & 1) * 32768) & 65535));
+                    accum += f[0] ^ f[3];
+                }
+            }
+            if (role == 7 || role == 9) {
+#pragma unroll
+                for (int q = 0; q < 32; q++) { facc += lut[(idx >> (q & 15)) & 15]; }
+                idx = idx * 1664525u + 1013904223u;
+            }
+            if (role == 7 || role == 10) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) *reinterpret_cast<u32x4 *>(img + ((waddr + q * 16 + (it & 1) * 32768) & 65535)) = u32x4{accum, idx, accum, idx};
+            }
+        }
+        r = (float)accum + facc;
+    }
     float s = r;
 #pragma unroll
     for (int i = 0; i < 8; i++) s += acc[i][0] + acc[i][7];
@@ -105,7 +134,9 @@ int main() {
         {1, 2, "MFMA | VALU"}, {2, 1, "VALU | MFMA"}, {3, 0, "LDS  | idle"}, {3, 3, "LDS  | LDS"}, {1, 3, "MFMA | LDS"},
         {3, 1, "LDS  | MFMA"}, {4, 0, "MFMA+VALU one stream | idle"}, {4, 4, "MFMA+VALU | MFMA+VALU"},
         {5, 0, "MFMA+6xb128 prefetched | idle"}, {5, 5, "MFMA+6xb128 prefetched | same"},
-        {6, 0, "MFMA+6xb128 in place | idle"}, {6, 6, "MFMA+6xb128 in place | same"}};
+        {6, 0, "MFMA+6xb128 in place | idle"}, {6, 6, "MFMA+6xb128 in place | same"},
+        {7, 7, "LDS k-step mix (all 8 waves)"}, {8, 8, "  only 24 x ds_read_b128"}, {9, 9, "  only 32 x ds_read_b32 table"},
+        {10, 10, "  only 4 x ds_write_b128"}};
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     for (auto &m : modes) {
