@@ -4,7 +4,7 @@
 //                (reference: functional.py:788-793; Metal kernel int8_matmul_dequant mm:155-196)
 //   linear_int8  16-bit activations x int8 weights decoded in the B-tile producer (gemm_tile.h)
 //                (reference: Linear8bit.forward nn/linear8bit.py:70-102; Metal int8_matmul_simd mm:203-305)
-#include "gemm_tile.h"
+#include "gemm256.h"
 
 namespace mbnb {
 
@@ -130,6 +130,153 @@ __global__ __launch_bounds__(256, 2) void k_gemm_i8(const int8_t *__restrict__ A
         }
 }
 
+// ------------------------------------------------------------------ 256 x 256 x 128 pipelined int8 GEMM
+// The large-problem kernel: the tile, wave grid, LDS images and fragment reads of k_gemm256p (gemm256.h)
+// with BOTH operands arriving by LDS-DMA (no decode): 8 x 1 KiB pieces per wave and k-step, issued one
+// per MFMA right after the barrier that frees the stage; one barrier per k-step between MFMA groups 2
+// and 3, next group's fragments read before the current group's MFMAs.  Requires K % 128 == 0.
+template <typename OutT>
+__global__ __launch_bounds__(512, 2) void k_gemm_i8_256(const int8_t *__restrict__ A, const int8_t *__restrict__ Bt,
+                                                        const float *__restrict__ sA, const float *__restrict__ sB,
+                                                        OutT *__restrict__ out, int64_t M, int64_t N, int64_t K) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave >> 2, wm = wave & 3;
+    const int64_t tiles_m = (M + 255) >> 8, tiles_n = (N + 255) >> 8;
+    const int64_t nwg = tiles_m * tiles_n;
+    int64_t bid = blockIdx.x;
+    {
+        const int64_t q = nwg / 8, r = nwg % 8, xcd = bid % 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+    }
+    int64_t tm, tn;
+    if ((tiles_m % 4 == 0) && (tiles_n % 8 == 0)) {
+        const int64_t patch = bid >> 5, within = bid & 31;
+        const int64_t patches_m = tiles_m >> 2;
+        tm = (patch % patches_m) * 4 + (within & 3);
+        tn = (patch / patches_m) * 8 + (within >> 2);
+    } else {
+        tm = bid % tiles_m;
+        tn = bid / tiles_m;
+    }
+    const int64_t m0 = tm << 8, n0 = tn << 8;
+
+    // DMA pieces: wave w moves rows 32w .. 32w+31 of both images (4 pieces of 8 rows each), swizzle on the source
+    const int8_t *a_src[4], *b_src[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int row = 8 * (wave * 4 + i) + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        int64_t m = m0 + row, n = n0 + row;
+        m = m < M ? m : M - 1;
+        n = n < N ? n : N - 1;
+        a_src[i] = A + m * K + 16 * c;
+        b_src[i] = Bt + n * K + 16 * c;
+    }
+    auto issue_piece = [&](int stage, int64_t k0, int p) {  // p 0..3: A pieces, 4..7: B pieces
+        const int i = p & 3;
+        auto g = (const __attribute__((address_space(1))) void *)((p < 4 ? a_src[i] : b_src[i]) + k0);
+        auto l = (__attribute__((address_space(3))) void *)(smem + (p < 4 ? P_A : P_B) + stage * P_IMG + (wave * 4 + i) * 1024);
+        __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
+    };
+    const int fr = lane & 31, fh = lane >> 5;
+    int fw[4], fx[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        const int f = fr * ROW_BYTES + (((2 * s + fh) ^ ((fr >> 1) & 7)) << 4);
+        fw[s] = P_B + wn * 128 * ROW_BYTES + f;
+        fx[s] = P_A + wm * 64 * ROW_BYTES + f;
+    }
+    auto read_frags = [&](int stage, int s, i32x4 (&wf)[4], i32x4 (&xf)[2]) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) wf[i] = *reinterpret_cast<const i32x4 *>(smem + fw[s] + stage * P_IMG + i * 32 * ROW_BYTES);
+#pragma unroll
+        for (int j = 0; j < 2; j++) xf[j] = *reinterpret_cast<const i32x4 *>(smem + fx[s] + stage * P_IMG + j * 32 * ROW_BYTES);
+    };
+    i32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0;
+
+    const int64_t nk = K >> 7;
+    const int64_t k_last = (nk - 1) << 7;
+    auto kclamp = [&](int64_t t) { return t < nk ? t << 7 : k_last; };
+
+#pragma unroll
+    for (int p = 0; p < 8; p++) issue_piece(0, 0, p);
+#pragma unroll
+    for (int p = 0; p < 8; p++) issue_piece(1, kclamp(1), p);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // tile 0 landed (tile 1 still in flight)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    i32x4 wfA[4], xfA[2], wfB[4], xfB[2];
+    read_frags(0, 0, wfA, xfA);
+
+    auto group = [&](const i32x4 (&wf)[4], const i32x4 (&xf)[2], auto &&filler) {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[i], xf[j], acc[i][j], 0, 0, 0);
+                filler(i * 2 + j);
+            }
+    };
+    auto kstep = [&](auto cc, int64_t j) {
+        constexpr int C = decltype(cc)::value, Nn = C ^ 1;
+        read_frags(C, 1, wfB, xfB);
+        __builtin_amdgcn_sched_barrier(0);
+        group(wfA, xfA, [](int) {});
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(C, 2, wfA, xfA);
+        __builtin_amdgcn_sched_barrier(0);
+        group(wfB, xfB, [](int) {});
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(C, 3, wfB, xfB);
+        __builtin_amdgcn_sched_barrier(0);
+        group(wfA, xfA, [](int) {});
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // tile j+1 landed (issued one k-step ago)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                        // stage Nn complete, stage C free
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(Nn, 0, wfA, xfA);
+        __builtin_amdgcn_sched_barrier(0);
+        group(wfB, xfB, [&](int r) { issue_piece(C, kclamp(j + 2), r); });  // one DMA piece behind each MFMA
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int64_t j = 0; j < nk; j += 2) {
+        kstep(std::integral_constant<int, 0>{}, j);
+        if (j + 1 < nk) kstep(std::integral_constant<int, 1>{}, j + 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int64_t m = m0 + wm * 64 + j * 32 + fr;
+            if (m >= M) continue;
+            const float sa = sA[m] / 127.0f;
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int64_t n = n0 + wn * 128 + i * 32 + 8 * g + 4 * fh;
+                if (n >= N) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const float sb = (n + e < N) ? sB[n + e] / 127.0f : 0.0f;
+                    v[e] = (float)acc[i][j][4 * g + e] * sa * sb;
+                }
+                store4(out + m * N + n, v, n, N);
+            }
+        }
+}
+
 // odd K (not a multiple of 16) or unaligned pointers: one wave per output element row
 template <typename OutT>
 __global__ __launch_bounds__(256) void k_matmul_i8_generic(const int8_t *__restrict__ A, const int8_t *__restrict__ B,
@@ -159,6 +306,29 @@ int matmul_int8_dispatch(const int8_t *A, const int8_t *B, const float *sA, cons
     }
     int8_t *Bt = static_cast<int8_t *>(workspace);
     hipLaunchKernelGGL(k_transpose_i8, dim3((unsigned)((N + 63) / 64), (unsigned)((K + 63) / 64)), dim3(256), 0, st, B, Bt, K, N);
+    if ((K % 128 == 0) && ((M + 255) / 256) * ((N + 255) / 256) >= 96) {
+        const int64_t tiles256 = ((M + 255) / 256) * ((N + 255) / 256);
+        constexpr int lds256 = 4 * P_IMG;
+#define MBNB_I8_256(OT)                                                                                              \
+    do {                                                                                                             \
+        auto kern = k_gemm_i8_256<OT>;                                                                               \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                     \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds256);                      \
+        if (e != hipSuccess) {                                                                                       \
+            set_error("matmul_int8: hipFuncSetAttribute failed: %s", hipGetErrorString(e));                          \
+            return (int)e;                                                                                           \
+        }                                                                                                            \
+        hipLaunchKernelGGL(kern, dim3((unsigned)tiles256), dim3(512), lds256, st, A, Bt, sA, sB, static_cast<OT *>(out), M, N, K); \
+    } while (0)
+        switch (out_dtype) {
+            case MBNB_F16: MBNB_I8_256(f16_t); break;
+            case MBNB_BF16: MBNB_I8_256(bf16_t); break;
+            default: MBNB_I8_256(float); break;
+        }
+#undef MBNB_I8_256
+        set_kernel_name("i8_mfma256");
+        return check_launch("matmul_int8(mfma256)");
+    }
     const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
     constexpr int lds = 2 * (128 + 128) * ROW_BYTES;
 #define MBNB_I8(OT)                                                                                                  \
@@ -209,6 +379,24 @@ static int launch_linear_int8(const void *X, int64_t M, int64_t K, const int8_t 
     T *o = static_cast<T *>(out);
     if constexpr (sizeof(T) == 2) {
         const bool fast = (K % 16 == 0) && (((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(W)) & 15) == 0) && M > 4;
+        if (fast && (K % 64 == 0) && ((M + 255) / 256) * ((N + 255) / 256) >= 96) {
+            // large problems: the 256 x 256 one-workgroup-per-CU kernel with the int8 -> 16-bit decode in the
+            // weight-tile producer (gemm256.h, k_gemm256)
+            using P = I8ProducerRT<T>;
+            typename P::Params wp{W, scales, N, K};
+            auto kern = k_gemm256<T, P>;
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS);
+            if (e != hipSuccess) {
+                set_error("linear_int8: hipFuncSetAttribute(256) failed: %s", hipGetErrorString(e));
+                return (int)e;
+            }
+            const int64_t tiles = ((M + 255) / 256) * ((N + 255) / 256);
+            const int od = std::is_same<T, f16_t>::value ? MBNB_F16 : MBNB_BF16;
+            hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(512), G256_LDS, st, x, wp, b, static_cast<void *>(o), od, M, N, K);
+            set_kernel_name("w8a16_mfma256");
+            return check_launch("linear_int8(mfma256)");
+        }
         if (fast) {
             using P = I8Producer<T>;
             typename P::Params wp{W, scales, N, K};
