@@ -94,12 +94,20 @@ def main():
     if not torch.cuda.is_available():
         print(json.dumps({"error": "no GPU visible; bench.py measures the HIP path only"}))
         sys.exit(2)
+    # BENCH_REHEARSE=1: every rank uses cuda:0 and the gloo backend -- lets the N > 1 code path be exercised on a
+    # one-GPU box (RCCL refuses two ranks on one device); numbers from such a run mean nothing.
+    rehearse = os.environ.get("BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import mps_bitsandbytes_amd as bnb
     from mps_bitsandbytes_amd import _native, synthetic
@@ -149,12 +157,20 @@ def main():
             del W
             X = torch.randn(e_row - s_row, K, generator=g, device=dev, dtype=torch.float32).to(dt)
             if distributed and not args.no_gather:
-                gathered = torch.empty(M_global, N, dtype=dt, device=dev)
+                # two result buffers: the all-gather of step i (RCCL's own stream, async_op) overlaps the GEMM of
+                # step i+1; a buffer is reused only after the gather that filled it two steps earlier has completed
+                gathered = [torch.empty(M_global, N, dtype=dt, device=dev) for _ in range(2)]
+            pending = [None, None]
+            counter = [0]
 
             def step():
                 y = bnb.matmul_4bit(X, packed, state)
                 if gathered is not None:
-                    dist.all_gather_into_tensor(gathered, y)
+                    i = counter[0] & 1
+                    counter[0] += 1
+                    if pending[i] is not None:
+                        pending[i].wait()
+                    pending[i] = dist.all_gather_into_tensor(gathered[i], y, async_op=True)
             flops_per_step = 2.0 * M * N * K
     else:
         A = torch.randint(-127, 128, (M, K), generator=g, device=dev, dtype=torch.int8)
@@ -175,13 +191,17 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    if gathered is not None:
+        for w in pending:
+            if w is not None:
+                w.wait()
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kernel_name = _native.last_kernel()
@@ -202,7 +222,7 @@ def main():
                                   "int8_4096": "rowwise INT8 matmul_int8 4096x4096x4096 on int8 MFMA",
                                   "nf4_m1": "fused NF4 dequant+GEMV, weight 4096x4096 fp16 bs64, M=1, rotating over 64 layers"}[wl],
                      "global_rows": M_global, "rows_per_gpu": M, "N": N, "K": K,
-                     "parallelism": f"rows sharded x{world}, weights replicated" + (", all-gather of outputs (RCCL)" if gathered is not None else ""),
+                     "parallelism": f"rows sharded x{world}, weights replicated" + (", all-gather of outputs (RCCL, async: overlaps the next step's GEMM)" if gathered is not None else ""),
                      "kernel": kernel_name}
     if wl == "nf4_m1":
         gbs = bytes_per_launch / (kern_ms * 1e-3) / 1e9

@@ -21,6 +21,9 @@ from .functional import (
     double_quant, dequant_absmax,
 )
 from .nn import Linear4bit, Linear8bit, Params4bit
+from .integration import (
+    BitsAndBytesConfig, quantize_model, replace_linear_with_4bit, replace_linear_with_8bit, get_memory_footprint,
+)
 
 
 def is_available() -> bool:
@@ -44,4 +47,5 @@ __all__ = [
     'quantize_rowwise', 'dequantize_rowwise', 'matmul_int8', 'linear_int8',
     'double_quant', 'dequant_absmax',
     'Linear4bit', 'Linear8bit', 'Params4bit',
+    'BitsAndBytesConfig', 'quantize_model', 'replace_linear_with_4bit', 'replace_linear_with_8bit', 'get_memory_footprint',
 ]

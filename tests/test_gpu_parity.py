@@ -426,3 +426,41 @@ def test_reference_envelope_tests():
     assert (fused.float() - unfused.float()).abs().max().item() < 0.1
     q, sc8 = bnb.quantize_rowwise(torch.full((8, 32), 0.5, dtype=torch.float16, device=DEV))
     assert (q == 127).all()                                                               # tests/test_advanced_linear.py:139-153
+
+
+def test_quantize_model_replaces_linears_and_matches_layerwise_oracle():
+    """integration.quantize_model: module-tree replacement with skip list, double quant wired."""
+    torch.manual_seed(0)
+
+    class MLP(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.up = torch.nn.Linear(128, 256)
+            self.act = torch.nn.GELU()
+            self.down = torch.nn.Linear(256, 64)
+            self.lm_head = torch.nn.Linear(64, 32)
+
+        def forward(self, x):
+            return self.lm_head(self.down(self.act(self.up(x))))
+
+    ref = MLP().half()
+    cfg = bnb.BitsAndBytesConfig(load_in_4bit=True, bnb_4bit_use_double_quant=True)
+    import copy
+    qm = bnb.quantize_model(copy.deepcopy(ref), quantization_config=cfg, modules_to_not_convert=["lm_head"])
+    assert isinstance(qm.up, bnb.Linear4bit) and isinstance(qm.down, bnb.Linear4bit) and isinstance(qm.lm_head, torch.nn.Linear)
+    assert qm.up.weight_quant_state.state2 is not None and qm.up.weight.device.type == "cuda"
+    x = synthetic.normal((5, 128), torch.float16, seed=200).to(DEV)
+    y = qm(x)
+    # layer-wise reference: oracle matmul for the quantized layers, torch for the rest
+    h = x.cpu()
+    for name in ("up", "down"):
+        lin = getattr(ref, name)
+        p, a, st2 = oracle.quantize_4bit(lin.weight.data, 64, "nf4", True)
+        h = oracle.matmul_4bit(h, p, a, tuple(lin.weight.shape), 64, "nf4", torch.float16, lin.bias.data, None, st2)
+        if name == "up":
+            h = torch.nn.functional.gelu(h.float()).half()
+    y_ref = torch.nn.functional.linear(h.float(), ref.lm_head.weight.float(), ref.lm_head.bias.float())
+    assert rel_fro(y, y_ref) < 5e-3
+    q8 = bnb.quantize_model(copy.deepcopy(ref), load_in_8bit=True)
+    assert isinstance(q8.up, bnb.Linear8bit) and q8(x).shape == (5, 32)
+    assert bnb.get_memory_footprint(qm)["quantized_params"] > 0

@@ -122,3 +122,26 @@ def test_row_shard_partitions_exactly():
         assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         row_shard(8, 2, 2)
+
+
+def test_bitsandbytes_config_mirrors_reference():
+    cfg = bnb.BitsAndBytesConfig(load_in_4bit=True, bnb_4bit_quant_type="fp4", bnb_4bit_compute_dtype=torch.bfloat16,
+                                 bnb_4bit_use_double_quant=True)
+    assert cfg.is_quantizable and cfg.quantization_method == "bitsandbytes_4bit" and cfg.llm_int8_skip_modules == []
+    d = cfg.to_dict()
+    assert sorted(d) == ["bnb_4bit_compute_dtype", "bnb_4bit_quant_type", "bnb_4bit_use_double_quant", "llm_int8_skip_modules",
+                         "llm_int8_threshold", "load_in_4bit", "load_in_8bit"]
+    back = bnb.BitsAndBytesConfig.from_dict(d)
+    assert back.bnb_4bit_compute_dtype == torch.bfloat16 and back.bnb_4bit_quant_type == "fp4" and back.load_in_4bit
+    assert bnb.BitsAndBytesConfig().quantization_method == "none"
+    with pytest.raises(ValueError, match="both 4-bit and 8-bit"):
+        bnb.BitsAndBytesConfig(load_in_4bit=True, load_in_8bit=True)
+    with pytest.raises(ValueError, match="bnb_4bit_quant_type must be"):
+        bnb.BitsAndBytesConfig(bnb_4bit_quant_type="int4")
+
+
+def test_memory_footprint_counts_quantized_buffers():
+    m = torch.nn.Sequential(bnb.Linear4bit(64, 32, bias=False), bnb.Linear8bit(32, 16, bias=True))
+    fp = bnb.get_memory_footprint(m)
+    assert fp["quantized_params"] == 64 * 32 // 2 + 32 * 16
+    assert fp["total_params"] > 0 and fp["actual_size_gb"] > 0
