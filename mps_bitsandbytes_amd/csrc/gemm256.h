@@ -355,7 +355,7 @@ __device__ unsigned long long g_dbg_stamps[2][1024];
 #define MBNB_NOP4() do {} while (0)
 #define MBNB_NOP2() do {} while (0)
 
-template <typename T, bool NESTED, int ablate = 0>
+template <typename T, bool NESTED, int ablate = 0, bool AM4 = false>
 __global__ __launch_bounds__(512, 2) void k_gemm256p(const T *__restrict__ X, typename Q4ProducerRT<T, NESTED>::Params wp,
                                                      const T *__restrict__ bias, void *__restrict__ out_v, int out_dtype,
                                                      int64_t M, int64_t N, int64_t K) {
@@ -436,7 +436,9 @@ __global__ __launch_bounds__(512, 2) void k_gemm256p(const T *__restrict__ X, ty
             __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
         }
         const int64_t ai = am_row + ((k0 + 32 * b_half) >> wp.bs_shift);
-        if constexpr (!NESTED) {
+        if constexpr (AM4) {
+            // absmax arrives separately, four k-steps at a time (issue_am4)
+        } else if constexpr (!NESTED) {
             auto g = (const __attribute__((address_space(1))) void *)(wp.am.f32 + ai);
             auto l = (__attribute__((address_space(3))) void *)(base + 8192 + wave * 256);
             __builtin_amdgcn_global_load_lds(g, l, 4, 0, 0);
@@ -450,6 +452,22 @@ __global__ __launch_bounds__(512, 2) void k_gemm256p(const T *__restrict__ X, ty
             __builtin_amdgcn_global_load_lds(g2, l2, 4, 0, 0);
         }
     };
+    // AM4 (blocksize 64, plain f32 absmax, K_weight % 256 == 0): a per-lane 4-byte absmax DMA every k-step pulls
+    // one 64-byte sector per lane -- 512 sector requests per CU and k-step for 2 KiB of data, as many as the
+    // whole activation tile.  Instead lanes 0-31 of a wave fetch 16 B = the absmax of FOUR consecutive
+    // k-steps of their row every fourth step (block b = tiles 4b..4b+3 -> slot b & 1).
+    constexpr int P_AM4 = P_RAW + 2 * RAW_BYTES;
+    int64_t am4_src_row = n0 + 32 * wave + (lane & 31);  // the row whose absmax this lane fetches
+    am4_src_row = am4_src_row < N ? am4_src_row : N - 1;
+    auto issue_am4 = [&](int64_t blk) {
+        const int64_t nb4 = wp.nblk >> 2;
+        const int64_t b = blk < nb4 ? blk : nb4 - 1;
+        if (lane < 32) {
+            auto g = (const __attribute__((address_space(1))) void *)(wp.am.f32 + am4_src_row * wp.nblk + 4 * b);
+            auto l = (__attribute__((address_space(3))) void *)(smem + P_AM4 + (int)(blk & 1) * 4096 + wave * 512);
+            __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
+        }
+    };
     // raw registers of the tile being decoded, by tile parity
     u32x4 rw[2];
     float ram[2];
@@ -457,7 +475,11 @@ __global__ __launch_bounds__(512, 2) void k_gemm256p(const T *__restrict__ X, ty
         constexpr int P = decltype(pp)::value;
         const char *base = smem + rs * RAW_BYTES;
         rw[P] = *reinterpret_cast<const u32x4 *>(base + raw_lane);
-        if constexpr (!NESTED) {
+        if constexpr (AM4) {
+            const int64_t t = k0 >> 6;  // (clamped) tile index
+            ram[P] = *reinterpret_cast<const float *>(smem + P_AM4 + (int)((t >> 2) & 1) * 4096 + wave * 512 +
+                                                      (b_row - 32 * wave) * 16 + (int)(t & 3) * 4);
+        } else if constexpr (!NESTED) {
             ram[P] = *reinterpret_cast<const float *>(base + raw_am);
         } else {
             const int64_t ai = am_row + ((k0 + 32 * b_half) >> wp.bs_shift);
@@ -589,6 +611,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm256p(const T *__restrict__ X, ty
     issue_a(0, 0);
     issue_raw(0, 0);
     issue_raw(1, kclamp(1));
+    if constexpr (AM4) issue_am4(0);
     MBNB_VMCNT(0);
     __syncthreads();  // code table, A(0) and this wave's raw(0), raw(1) visible
     load_raw(P0{}, 0, 0);
@@ -640,7 +663,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm256p(const T *__restrict__ X, ty
             finish_q(La, ram[Nn], 0, Nn);
             lookup_q(rw[Nn][1], Lb);
         }
-        if constexpr (!(ablate & 1)) { if (j > 0) issue_a(Nn, kclamp(j + 1), 2, 1); }
+        if constexpr (!(ablate & 1) && !(ablate & 8192)) { if (j > 0) issue_a(Nn, kclamp(j + 1), 2, 1); }
         if constexpr (ablate & 4096) interleave(I3{}, I2{}, I1{}, I1{});
         __builtin_amdgcn_sched_barrier(0);
         stamp();
@@ -655,7 +678,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm256p(const T *__restrict__ X, ty
             lookup_q(rw[Nn][2], La);
             lookup_q(rw[Nn][3], Lc);
         }
-        if constexpr (!(ablate & 1)) { if (j > 0) issue_a(Nn, kclamp(j + 1), 3, 1); }
+        if constexpr (!(ablate & 1) && !(ablate & 8192)) { if (j > 0) issue_a(Nn, kclamp(j + 1), 3, 1); }
         if constexpr (ablate & 4096) interleave(I4{}, I3{}, I1{}, I1{});
         __builtin_amdgcn_sched_barrier(0);
         stamp();
@@ -667,10 +690,14 @@ __global__ __launch_bounds__(512, 2) void k_gemm256p(const T *__restrict__ X, ty
             finish_q(Lc, ram[Nn], 3, Nn);
         }
         if constexpr (!(ablate & 2)) issue_raw(Nn, kclamp(j + 3));
+        const bool am_now = AM4 && (((j + 3) & 3) == 0);
+        if constexpr (AM4) { if (am_now) issue_am4((j + 3) >> 2); }
         if constexpr (ablate & 4096) interleave(I4{}, I1{}, I2{}, I2{});
         __builtin_amdgcn_sched_barrier(0);
         stamp();
-        if constexpr (NESTED) MBNB_VMCNT(3); else MBNB_VMCNT(2);  // R: all but raw(j+3): A(j+1) and raw(j+2) landed
+        // all but what this group just issued has landed: A(j+1), raw(j+2) (and older absmax blocks)
+        if constexpr (AM4) { if (am_now) { MBNB_VMCNT(2); } else { MBNB_VMCNT(1); } }
+        else if constexpr (NESTED) MBNB_VMCNT(3); else MBNB_VMCNT(2);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // own decode writes + fragment reads done
         __builtin_amdgcn_s_barrier();                         // stage Nn complete, stage C free
         asm volatile("" ::: "memory");
@@ -681,7 +708,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm256p(const T *__restrict__ X, ty
         load_raw(PC{}, C, kclamp(j + 2));  // raw(j+2) landed before the barrier above
         if constexpr (!(ablate & 8)) mfma_group(wfB, xfB);
         if constexpr (!(ablate & 4) && !(ablate & 2048)) lookup_q(rw[C][0], La);
-        if constexpr (!(ablate & 1)) issue_a(C, kclamp(j + 2), 0, 2);
+        if constexpr (!(ablate & 1)) issue_a(C, kclamp(j + 2), 0, (ablate & 8192) ? 4 : 2);
         if constexpr (ablate & 4096) interleave(I2{}, I2{}, I0{}, I2{});
         __builtin_amdgcn_sched_barrier(0);
         stamp();
@@ -1396,7 +1423,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm256pp(const T *__restrict__ X, t
 }
 
 template <bool NESTED> constexpr int gemm256p_lds_bytes() {
-    return P_RAW + 2 * (8192 + 2048 + (NESTED ? 2048 : 0));
+    return P_RAW + 2 * (8192 + 2048 + (NESTED ? 2048 : 0)) + (NESTED ? 0 : 8192);  // + absmax-by-4 slots (AM4 variant, plain absmax only)
 }
 
 }  // namespace mbnb

@@ -256,6 +256,12 @@ static int launch_matmul4(const void *A, int64_t M, int64_t K, const uint8_t *pa
                 using KernT = void (*)(const T *, typename P::Params, const T *, void *, int, int64_t, int64_t, int64_t);
                                 static const bool use_valu = getenv("MBNB_VALUDEC") != nullptr;  // debug A/B switch: slot-pinned + VALU decode
                 KernT kern = use_valu ? k_gemm256v<T, NESTED> : (use_pp ? k_gemm256pp<T, NESTED> : k_gemm256p<T, NESTED>);
+                if constexpr (!NESTED) {
+                    static const bool no_am4 = getenv("MBNB_NO_AM4") != nullptr;  // debug A/B switch
+                    static const bool burst = getenv("MBNB_DMA_BURST") != nullptr;  // debug A/B switch
+                    if (!use_valu && !use_pp && !no_am4 && blocksize == 64 && (K_weight % 256 == 0))
+                        kern = burst ? k_gemm256p<T, false, 8192, true> : k_gemm256p<T, false, 0, true>;
+                }
 #ifdef MBNB_ABLATION
                 if constexpr (std::is_same<T, bf16_t>::value && !NESTED) {
                     static const int abl = getenv("MBNB_ABLATE") ? atoi(getenv("MBNB_ABLATE")) : 0;
