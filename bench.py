@@ -40,7 +40,7 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=100)  # ~13 ms: the GPU clock needs a few ms of load to ramp
     ap.add_argument("--workload", default="nf4_m4096",
                     choices=["nf4_m4096", "nf4dq_ffn", "int8_4096", "nf4_m1"],
                     help="nf4_m4096 = the BASELINE metric (default); the others are BASELINE configs 3, 4 and 2")

@@ -22,6 +22,7 @@
 #include "gemm_tile.h"
 
 namespace mbnb {
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void fill_code_lut_rt(float *lut, int tid, int qt) {
     if (tid < 16) {
@@ -355,7 +356,7 @@ __device__ unsigned long long g_dbg_stamps[2][1024];
 #define MBNB_NOP4() do {} while (0)
 #define MBNB_NOP2() do {} while (0)
 
-template <typename T, bool NESTED, int ablate = 0, bool AM4 = false>
+template <typename T, bool NESTED, int ablate = 0, bool AM4 = false, bool BLUT = false>
 __global__ __launch_bounds__(512, 2) void k_gemm256p(const T *__restrict__ X, typename Q4ProducerRT<T, NESTED>::Params wp,
                                                      const T *__restrict__ bias, void *__restrict__ out_v, int out_dtype,
                                                      int64_t M, int64_t N, int64_t K) {
@@ -395,6 +396,16 @@ __global__ __launch_bounds__(512, 2) void k_gemm256p(const T *__restrict__ X, ty
     const int64_t m0 = tm << 8, n0 = tn << 8;
 
     fill_code_lut_rt(s_lut, tid, wp.qt);
+    // byte table: entry b = (code[b & 15], code[b >> 4]) as two f32 -> one ds_read_b64 per packed byte
+    __shared__ __attribute__((aligned(2048))) float s_lut2[512];
+    if constexpr (BLUT) {
+        const int b = tid >> 1, nib = (tid & 1) ? (b >> 4) : (b & 15);
+        float v = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            if (nib == i) v = (wp.qt == MBNB_NF4) ? nf4_code(i) : fp4_code(i);
+        s_lut2[tid] = v;
+    }
 
     // ---- activation pieces: wave w moves pieces 4w..4w+3 (8 rows x 128 B each), swizzle on the source
     const T *a_src[4];
@@ -497,7 +508,23 @@ __global__ __launch_bounds__(512, 2) void k_gemm256p(const T *__restrict__ X, ty
     //   lookup_q: byte offsets 4*idx with one v_bfe_u32 per nibble (odd nibbles: 6-bit field at 8j+2 of
     //             w & 0xF0F0F0F0; even: byte j of (w << 2) & 0x3C3C3C3C), then 8 ds_read_b32
     //   finish_q: value = code * absmax in f32 -> RNE 16-bit (the reference's dequantize_4bit bits) -> ds_write_b128
+    uint32_t dbg_sink = 0;
     auto lookup_q = [&](uint32_t w, float (&L)[8]) {
+        if constexpr (ablate & 65536) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) L[j] = __builtin_bit_cast(float, w + (uint32_t)j);
+            return;
+        }
+        if constexpr (BLUT) {
+            const char *lut2 = reinterpret_cast<const char *>(s_lut2);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const f32x2 v = *reinterpret_cast<const f32x2 *>(lut2 + (((w >> (8 * j)) & 0xFFu) << 3));
+                L[2 * j] = v[0];
+                L[2 * j + 1] = v[1];
+            }
+            return;
+        }
         const uint32_t wo = w & 0xF0F0F0F0u;
         const uint32_t we = (w << 2) & 0x3C3C3C3Cu;
         const char *lutb = reinterpret_cast<const char *>(s_lut);
@@ -510,7 +537,17 @@ __global__ __launch_bounds__(512, 2) void k_gemm256p(const T *__restrict__ X, ty
     auto finish_q = [&](const float (&L)[8], float am, int d, int stage) {
         u32x4 o;
 #pragma unroll
-        for (int j = 0; j < 4; j++) o[j] = pack2<T>(L[2 * j] * am, L[2 * j + 1] * am);
+        for (int j = 0; j < 4; j++) {
+            if constexpr (ablate & 65536) {
+                o[j] = __builtin_bit_cast(uint32_t, L[2 * j]) ^ __builtin_bit_cast(uint32_t, am);
+            } else if constexpr (BLUT) {
+                const f32x2 pr = f32x2{L[2 * j], L[2 * j + 1]} * f32x2{am, am};  // v_pk_mul_f32: two IEEE products
+                o[j] = pack2<T>(pr[0], pr[1]);
+            } else {
+                o[j] = pack2<T>(L[2 * j] * am, L[2 * j + 1] * am);
+            }
+        }
+        if constexpr (ablate & 32768) { dbg_sink ^= o[0] ^ o[1] ^ o[2] ^ o[3]; return; }
         *reinterpret_cast<u32x4 *>(smem + stage * P_IMG + bw_off[d]) = o;
     };
     float La[8], Lb[8], Lc[8];   // looked-up code values in flight: quarters (0 then 2), 1, 3
@@ -718,6 +755,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm256p(const T *__restrict__ X, ty
         if (j + 1 < nk) kstep(std::integral_constant<int, 1>{}, j + 1);
     }
     MBNB_VMCNT(0);
+    if constexpr (ablate & 32768) { if (dbg_sink == 0x12345u) acc[0][0][0] += 1.0f; }
 
     // ---- epilogue: every wave is past the last barrier-protected LDS read once all waves drained their
     // fragment reads; the extra barrier makes the stage memory reusable as store staging
@@ -760,7 +798,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm256p(const T *__restrict__ X, ty
 // fragment reads, image writes and the LDS-DMA (measured LDS time of k_gemm256p's mix: 2140 cycles per
 // k-step vs 2048 of MFMA -- tools/coexec_probe.hip -- so the table reads had to leave the LDS).
 // =====================================================================================
-template <typename T, bool NESTED, int ablate = 0>
+template <typename T, bool NESTED, int ablate = 0, bool AM4 = false>
 __global__ __launch_bounds__(512, 2) void k_gemm256v(const T *__restrict__ X, typename Q4ProducerRT<T, NESTED>::Params wp,
                                                      const T *__restrict__ bias, void *__restrict__ out_v, int out_dtype,
                                                      int64_t M, int64_t N, int64_t K) {
@@ -841,7 +879,8 @@ __global__ __launch_bounds__(512, 2) void k_gemm256v(const T *__restrict__ X, ty
             __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
         }
         const int64_t ai = am_row + ((k0 + 32 * b_half) >> wp.bs_shift);
-        if constexpr (!NESTED) {
+        if constexpr (AM4) {
+        } else if constexpr (!NESTED) {
             auto g = (const __attribute__((address_space(1))) void *)(wp.am.f32 + ai);
             auto l = (__attribute__((address_space(3))) void *)(base + 8192 + wave * 256);
             __builtin_amdgcn_global_load_lds(g, l, 4, 0, 0);
@@ -855,6 +894,18 @@ __global__ __launch_bounds__(512, 2) void k_gemm256v(const T *__restrict__ X, ty
             __builtin_amdgcn_global_load_lds(g2, l2, 4, 0, 0);
         }
     };
+    constexpr int P_AM4 = P_RAW + 2 * RAW_BYTES;
+    int64_t am4_src_row = n0 + 32 * wave + (lane & 31);
+    am4_src_row = am4_src_row < N ? am4_src_row : N - 1;
+    auto issue_am4 = [&](int64_t blk) {
+        const int64_t nb4 = wp.nblk >> 2;
+        const int64_t b = blk < nb4 ? blk : nb4 - 1;
+        if (lane < 32) {
+            auto g = (const __attribute__((address_space(1))) void *)(wp.am.f32 + am4_src_row * wp.nblk + 4 * b);
+            auto l = (__attribute__((address_space(3))) void *)(smem + P_AM4 + (int)(blk & 1) * 4096 + wave * 512);
+            __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
+        }
+    };
     // raw registers of the tile being decoded, by tile parity
     u32x4 rw[2];
     float ram[2];
@@ -862,7 +913,9 @@ __global__ __launch_bounds__(512, 2) void k_gemm256v(const T *__restrict__ X, ty
         constexpr int P = decltype(pp)::value;
         const char *base = smem + rs * RAW_BYTES;
         rw[P] = *reinterpret_cast<const u32x4 *>(base + raw_lane);
-        if constexpr (!NESTED) {
+        if constexpr (AM4) {  // prologue only: tiles 0 and 1, both in absmax block 0
+            ram[P] = *reinterpret_cast<const float *>(smem + P_AM4 + wave * 512 + (b_row - 32 * wave) * 16 + (int)((k0 >> 6) & 3) * 4);
+        } else if constexpr (!NESTED) {
             ram[P] = *reinterpret_cast<const float *>(base + raw_am);
         } else {
             const int64_t ai = am_row + ((k0 + 32 * b_half) >> wp.bs_shift);
@@ -994,6 +1047,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm256v(const T *__restrict__ X, ty
     issue_a(0, 0);
     issue_raw(0, 0);
     issue_raw(1, kclamp(1));
+    if constexpr (AM4) issue_am4(0);
     MBNB_VMCNT(0);
     __syncthreads();  // code table, A(0) and this wave's raw(0), raw(1) visible
     load_raw(P0{}, 0, 0);
@@ -1020,7 +1074,11 @@ __global__ __launch_bounds__(512, 2) void k_gemm256v(const T *__restrict__ X, ty
         const int rs = (int)(t & 1);
         const char *base = smem + rs * RAW_BYTES;
         rw1 = *reinterpret_cast<const u32x4 *>(base + raw_lane);
-        if constexpr (!NESTED) {
+        if constexpr (AM4) {
+            const int64_t tc = t < nk ? t : nk - 1;
+            ram1 = *reinterpret_cast<const float *>(smem + P_AM4 + (int)((tc >> 2) & 1) * 4096 + wave * 512 +
+                                                    (b_row - 32 * wave) * 16 + (int)(tc & 3) * 4);
+        } else if constexpr (!NESTED) {
             ram1 = *reinterpret_cast<const float *>(base + raw_am);
         } else {
             const int64_t ai = am_row + ((kclamp(t) + 32 * b_half) >> wp.bs_shift);
@@ -1036,10 +1094,15 @@ __global__ __launch_bounds__(512, 2) void k_gemm256v(const T *__restrict__ X, ty
 #define KS_LOAD_RAW1(tile) load_raw1(tile)
 #define KS_WRITEV(par, q) *reinterpret_cast<u32x4 *>(smem + (par) * P_IMG + bw_off[q]) = u32x4{ov[0], ov[1], ov[2], ov[3]}
 #define KS_DMA_A(stage, tile, piece) issue_a(stage, kclamp(tile), piece, 1)
-#define KS_DMA_RAW(slot, tile) issue_raw(slot, kclamp(tile))
+#define KS_DMA_RAW(slot, tile)                                                         \
+    do {                                                                               \
+        issue_raw(slot, kclamp(tile));                                                 \
+        if constexpr (AM4) { if ((((tile)) & 3) == 0) issue_am4(((tile)) >> 2); }      \
+    } while (0)
 #define KS_BARRIER()                                                                                   \
     do {                                                                                               \
-        if constexpr (NESTED) MBNB_VMCNT(3); else MBNB_VMCNT(2); /* all but raw(j+3) landed */          \
+        if constexpr (AM4) { if (((j + 3) & 3) == 0) { MBNB_VMCNT(2); } else { MBNB_VMCNT(1); } }      \
+        else if constexpr (NESTED) MBNB_VMCNT(3); else MBNB_VMCNT(2); /* all but raw(j+3) landed */    \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                             \
         __builtin_amdgcn_s_barrier();                                                                  \
         asm volatile("" ::: "memory");                                                                 \

@@ -13,6 +13,7 @@
 // result to the weight dtype, then a cast to the requested output dtype.
 #include <cstdlib>
 #include <type_traits>
+#include <utility>
 
 #include "gemm256.h"
 
@@ -78,6 +79,12 @@ __global__ __launch_bounds__(256) void k_matmul4_generic(const T *__restrict__ X
 // resident, shared by the NR rows).  Decode = LDS table lookup * absmax -> 16-bit (the exact
 // reference weight bits), contraction = v_dot2 into f32.
 // =====================================================================================
+template <int... I, class F> __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F &&f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F> __device__ __forceinline__ void static_for(F &&f) {
+    static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F &&>(f));
+}
 template <typename T> struct Dot2;
 template <> struct Dot2<f16_t> {
     static __device__ __forceinline__ float run(uint32_t a, uint32_t b, float c) {
@@ -126,38 +133,76 @@ __global__ __launch_bounds__(256) void k_gemv4(const T *__restrict__ X, const ui
 #pragma unroll
     for (int i = 0; i < MT; i++) xrow[i] = X + ((m0 + i < M) ? m0 + i : M - 1) * K;
 
-    fill_code_lut<QT>(lut, threadIdx.x);
-    if constexpr (XLDS) {
-#pragma unroll
-        for (int i = 0; i < MT; i++)
-            for (int64_t k = (int64_t)threadIdx.x * 8; k < K; k += 256 * 8)
-                *reinterpret_cast<u32x4 *>(xs + (i * K + k) * 2) = *reinterpret_cast<const u32x4 *>(xrow[i] + k);
-    }
-    __syncthreads();
-    for (int64_t kbase = 0; kbase < K; kbase += 2048 * KU) {
-        u32x4 wq[KU][NR];
-        float a[KU][NR];
-        float vf[KU];
-        u32x4 xv[KU][MT][4];
+    // The packed weights and absmax of trip t+1 are requested before trip t is decoded, and those of trip 0
+    // before the prologue (code table, activation staging, barrier): HBM latency overlaps the prologue.
+    // K % 32 == 0 here, so a lane's 32-k chunk is entirely inside or outside [0, K).  Outside: load from
+    // k = 0 (in bounds) and zero the absmax, so the products vanish -- no branch, no select between a load
+    // and its use.
+    u32x4 wq[KU][NR], wq_n[KU][NR];
+    float a[KU][NR], a_n[KU][NR];
+    float vf[KU], vf_n[KU];
+    auto request_w = [&](int64_t kbase) {
 #pragma unroll
         for (int u = 0; u < KU; u++) {
-            // K % 32 == 0 here, so a lane's 32-k chunk is entirely inside or outside [0, K).  Outside:
-            // load from k = 0 (in bounds) and zero the absmax, so the products vanish -- no branch,
-            // no select between a load and its use.
             const int64_t k0 = kbase + u * 2048 + lane * 32;
             const bool wvalid = k0 < K;
             const int64_t kc = wvalid ? k0 : 0;
-            vf[u] = wvalid ? 1.0f : 0.0f;
+            vf_n[u] = wvalid ? 1.0f : 0.0f;
 #pragma unroll
             for (int r = 0; r < NR; r++) {
-                wq[u][r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(wrow[r] + (kc >> 1)));
-                a[u][r] = load_absmax<NESTED>(am, arow[r] + (kc >> bs_shift));
+                wq_n[u][r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(wrow[r] + (kc >> 1)));
+                a_n[u][r] = load_absmax<NESTED>(am, arow[r] + (kc >> bs_shift));
             }
+        }
+    };
+    // activations -> LDS by LDS-DMA (no registers, no wait before the weight requests); rows are padded to
+    // Kp = K rounded up to 2048 so that whole-wave 1 KiB pieces never run past the allocation
+    const int64_t Kp = (K + 2047) & ~(int64_t)2047;
+    if constexpr (XLDS) {
+#pragma unroll
+        for (int i = 0; i < MT; i++)
+            for (int64_t kb = 0; kb < K; kb += 2048) {
+                const int64_t k = kb + (int64_t)threadIdx.x * 8;
+                auto g = (const __attribute__((address_space(1))) void *)(xrow[i] + (k < K ? k : 0));
+                auto l = (__attribute__((address_space(3))) void *)(xs + (i * Kp + kb) * 2 + (threadIdx.x >> 6) * 1024);
+                __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
+            }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    request_w(0);
+    __builtin_amdgcn_sched_barrier(0);
+    fill_code_lut<QT>(lut, threadIdx.x);
+    if constexpr (XLDS) {
+        // vmcnt is in order: everything older than the KU*NR weight (+ absmax) requests has landed
+        constexpr int NW = KU * NR * (NESTED ? 3 : 2);
+        static_assert(NW <= 63, "vmcnt range");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW) : "memory");
+    }
+    // raw barrier: __syncthreads() would also wait for the weight requests (its fence drains vmcnt)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    for (int64_t kbase = 0; kbase < K; kbase += 2048 * KU) {
+        u32x4 xv[KU][MT][4];
+#pragma unroll
+        for (int u = 0; u < KU; u++) {
+            vf[u] = vf_n[u];
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                wq[u][r] = wq_n[u][r];
+                a[u][r] = a_n[u][r];
+            }
+        }
+        if (kbase + 2048 * KU < K) request_w(kbase + 2048 * KU);
+#pragma unroll
+        for (int u = 0; u < KU; u++) {
+            const int64_t k0 = kbase + u * 2048 + lane * 32;
+            const int64_t kc = k0 < K ? k0 : 0;
 #pragma unroll
             for (int c = 0; c < 4; c++)
 #pragma unroll
                 for (int i = 0; i < MT; i++) {
-                    if constexpr (XLDS) xv[u][i][c] = *reinterpret_cast<const u32x4 *>(xs + (i * K + kc + 8 * c) * 2);
+                    if constexpr (XLDS) xv[u][i][c] = *reinterpret_cast<const u32x4 *>(xs + (i * Kp + kc + 8 * c) * 2);
                     else xv[u][i][c] = *reinterpret_cast<const u32x4 *>(xrow[i] + kc + 8 * c);
                 }
         }
@@ -167,27 +212,44 @@ __global__ __launch_bounds__(256) void k_gemv4(const T *__restrict__ X, const ui
         for (int u = 0; u < KU; u++)
 #pragma unroll
             for (int r = 0; r < NR; r++) a[u][r] *= vf[u];
+        // Decode, software-pipelined over the KU*NR*4 quarters (8 k each): the table lookups of quarter q+1
+        // are issued before quarter q is multiplied, so their LDS latency is not waited for in place.
+        constexpr int NQ = KU * NR * 4;
+        float L[2][8];
+        auto lookup = [&](auto qq, float (&Lq)[8]) {
+            constexpr int q = decltype(qq)::value;
+            constexpr int u = q / (NR * 4), r = (q / 4) % NR, c = q % 4;
+            const uint32_t w = wq[u][r][c];
+            {
+                // byte offsets 4*idx into the code table with one v_bfe_u32 per nibble (see gemm256.h)
+                const uint32_t wo = w & 0xF0F0F0F0u;
+                const uint32_t we = (w << 2) & 0x3C3C3C3Cu;
+                const char *lutb = reinterpret_cast<const char *>(lut);
 #pragma unroll
-        for (int u = 0; u < KU; u++)
-#pragma unroll
-            for (int r = 0; r < NR; r++) {
-#pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    const uint32_t w = wq[u][r][c];
-                    // byte offsets 4*idx into the code table with one v_bfe_u32 per nibble (see gemm256.h)
-                    const uint32_t wo = w & 0xF0F0F0F0u;
-                    const uint32_t we = (w << 2) & 0x3C3C3C3Cu;
-                    const char *lutb = reinterpret_cast<const char *>(lut);
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const float lo = *reinterpret_cast<const float *>(lutb + bfe_u32(we, 8 * j, 8)) * a[u][r];
-                        const float hi = *reinterpret_cast<const float *>(lutb + bfe_u32(wo, 8 * j + 2, 6)) * a[u][r];
-                        const uint32_t wp = pack2<T>(lo, hi);
-#pragma unroll
-                        for (int i = 0; i < MT; i++) acc[r][i] = Dot2<T>::run(wp, xv[u][i][c][j], acc[r][i]);
-                    }
+                for (int j = 0; j < 4; j++) {
+                    Lq[2 * j] = *reinterpret_cast<const float *>(lutb + bfe_u32(we, 8 * j, 8));
+                    Lq[2 * j + 1] = *reinterpret_cast<const float *>(lutb + bfe_u32(wo, 8 * j + 2, 6));
                 }
             }
+        };
+        auto consume = [&](auto qq, const float (&Lq)[8]) {
+            constexpr int q = decltype(qq)::value;
+            constexpr int u = q / (NR * 4), r = (q / 4) % NR, c = q % 4;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const f32x2 pr = f32x2{Lq[2 * j], Lq[2 * j + 1]} * f32x2{a[u][r], a[u][r]};  // two IEEE f32 products
+                const uint32_t wp = pack2<T>(pr[0], pr[1]);
+#pragma unroll
+                for (int i = 0; i < MT; i++) acc[r][i] = Dot2<T>::run(wp, xv[u][i][c][j], acc[r][i]);
+            }
+        };
+        lookup(std::integral_constant<int, 0>{}, L[0]);
+        static_for<NQ>([&](auto qq) {
+            constexpr int q = decltype(qq)::value;
+            if constexpr (q + 1 < NQ) lookup(std::integral_constant<int, q + 1>{}, L[(q + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(qq, L[q & 1]);
+        });
     }
 #pragma unroll
     for (int r = 0; r < NR; r++)
@@ -224,18 +286,22 @@ static int launch_matmul4(const void *A, int64_t M, int64_t K, const uint8_t *pa
     if constexpr (is16) {
         if (fast_layout && M <= 16 && (K % 32 == 0)) {
             const int sh = ilog2(blocksize);
-            const bool xlds = (int64_t)8 * K * 2 <= 65536;  // largest MT rows fit the default dynamic-LDS limit
+            const int64_t Kp = (K + 2047) & ~(int64_t)2047;
+            const bool xlds = (int64_t)8 * Kp * 2 <= 65536;  // largest MT rows fit the default dynamic-LDS limit
 #define MBNB_GEMV(MT, NR, KU)                                                                                       \
     do {                                                                                                            \
         dim3 grid((unsigned)((N + 4 * NR - 1) / (4 * NR)), (unsigned)((M + MT - 1) / MT));                          \
         if (xlds)                                                                                                   \
-            hipLaunchKernelGGL((k_gemv4<T, OutT, QT, NESTED, MT, NR, KU, true>), grid, dim3(256), (size_t)MT * K * 2, st, \
-                               x, packed, am, b, o, M, N, K, K_weight, sh);                                         \
+            hipLaunchKernelGGL((k_gemv4<T, OutT, QT, NESTED, MT, NR, KU, true>), grid, dim3(256),                   \
+                               (size_t)MT * Kp * 2, st, x, packed, am, b, o, M, N, K, K_weight, sh);                \
         else                                                                                                        \
             hipLaunchKernelGGL((k_gemv4<T, OutT, QT, NESTED, MT, NR, KU, false>), grid, dim3(256), 0, st, x, packed, \
                                am, b, o, M, N, K, K_weight, sh);                                                    \
     } while (0)
-            if (M == 1) MBNB_GEMV(1, 1, 2);
+            // M = 1: two rows per wave once there are enough rows to fill the chip twice over (4 KiB of packed
+            // weights in flight per wave: +12 % streaming rate at N >= 8192, tools/gemv_sweep.py)
+            if (M == 1 && N >= 8192) MBNB_GEMV(1, 2, 2);
+            else if (M == 1) MBNB_GEMV(1, 1, 2);
             else if (M == 2) MBNB_GEMV(2, 1, 2);
             else if (M <= 4) MBNB_GEMV(4, 2, 1);
             else MBNB_GEMV(8, 1, 1);
@@ -255,12 +321,18 @@ static int launch_matmul4(const void *A, int64_t M, int64_t K, const uint8_t *pa
                 static const bool use_pp = getenv("MBNB_PINGPONG") != nullptr;  // debug A/B switch (default: lockstep schedule, faster as measured)
                 using KernT = void (*)(const T *, typename P::Params, const T *, void *, int, int64_t, int64_t, int64_t);
                                 static const bool use_valu = getenv("MBNB_VALUDEC") != nullptr;  // debug A/B switch: slot-pinned + VALU decode
-                KernT kern = use_valu ? k_gemm256v<T, NESTED> : (use_pp ? k_gemm256pp<T, NESTED> : k_gemm256p<T, NESTED>);
+                // production: k_gemm256p with the byte-table decode; plain f32 absmax at blocksize 64 additionally
+                // fetches absmax once per four k-steps (AM4).  The other variants are kept as measured alternatives.
+                static const bool no_blut = getenv("MBNB_NO_BLUT") != nullptr;  // debug A/B switch: 16-entry table decode
+                KernT kern = use_valu ? k_gemm256v<T, NESTED>
+                                      : (use_pp ? k_gemm256pp<T, NESTED>
+                                                : (no_blut ? k_gemm256p<T, NESTED> : k_gemm256p<T, NESTED, 0, false, true>));
                 if constexpr (!NESTED) {
                     static const bool no_am4 = getenv("MBNB_NO_AM4") != nullptr;  // debug A/B switch
-                    static const bool burst = getenv("MBNB_DMA_BURST") != nullptr;  // debug A/B switch
-                    if (!use_valu && !use_pp && !no_am4 && blocksize == 64 && (K_weight % 256 == 0))
-                        kern = burst ? k_gemm256p<T, false, 8192, true> : k_gemm256p<T, false, 0, true>;
+                    if (!no_am4 && !use_pp && blocksize == 64 && (K_weight % 256 == 0)) {
+                        if (use_valu) kern = k_gemm256v<T, false, 0, true>;
+                        else kern = no_blut ? k_gemm256p<T, false, 0, true> : k_gemm256p<T, false, 0, true, true>;
+                    }
                 }
 #ifdef MBNB_ABLATION
                 if constexpr (std::is_same<T, bf16_t>::value && !NESTED) {
@@ -268,7 +340,7 @@ static int launch_matmul4(const void *A, int64_t M, int64_t K, const uint8_t *pa
                     switch (abl) {
 #define MBNB_ABL(v) case v: kern = use_pp ? k_gemm256pp<T, NESTED, v> : k_gemm256p<T, NESTED, v>; break;
                         MBNB_ABL(1) MBNB_ABL(2) MBNB_ABL(3) MBNB_ABL(4) MBNB_ABL(8) MBNB_ABL(16) MBNB_ABL(12) MBNB_ABL(20)
-                        MBNB_ABL(24) MBNB_ABL(28) MBNB_ABL(31) MBNB_ABL(7) MBNB_ABL(23) MBNB_ABL(32) MBNB_ABL(64) MBNB_ABL(128) MBNB_ABL(256) MBNB_ABL(512) MBNB_ABL(520) MBNB_ABL(535) MBNB_ABL(1024) MBNB_ABL(2048) MBNB_ABL(2056) MBNB_ABL(4096) MBNB_ABL(4608) MBNB_ABL(516) MBNB_ABL(515) MBNB_ABL(528) MBNB_ABL(532) MBNB_ABL(519)
+                        MBNB_ABL(24) MBNB_ABL(28) MBNB_ABL(31) MBNB_ABL(7) MBNB_ABL(23) MBNB_ABL(32) MBNB_ABL(64) MBNB_ABL(128) MBNB_ABL(256) MBNB_ABL(512) MBNB_ABL(520) MBNB_ABL(535) MBNB_ABL(1024) MBNB_ABL(2048) MBNB_ABL(2056) MBNB_ABL(4096) MBNB_ABL(4608) MBNB_ABL(516) MBNB_ABL(515) MBNB_ABL(528) MBNB_ABL(532) MBNB_ABL(519) MBNB_ABL(32768) MBNB_ABL(65536) MBNB_ABL(98304)
 #undef MBNB_ABL
                         default: break;
                     }
