@@ -474,9 +474,21 @@ __global__ __launch_bounds__(512, 2) void k_gemm256p(const T *__restrict__ X, ty
         const int64_t nb4 = wp.nblk >> 2;
         const int64_t b = blk < nb4 ? blk : nb4 - 1;
         if (lane < 32) {
-            auto g = (const __attribute__((address_space(1))) void *)(wp.am.f32 + am4_src_row * wp.nblk + 4 * b);
-            auto l = (__attribute__((address_space(3))) void *)(smem + P_AM4 + (int)(blk & 1) * 4096 + wave * 512);
-            __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
+            if constexpr (!NESTED) {
+                auto g = (const __attribute__((address_space(1))) void *)(wp.am.f32 + am4_src_row * wp.nblk + 4 * b);
+                auto l = (__attribute__((address_space(3))) void *)(smem + P_AM4 + (int)(blk & 1) * 4096 + wave * 512);
+                __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
+            } else {
+                // double-quantised absmax: the dword holding the row's four int8 codes of this block (nblk % 4 == 0
+                // keeps it aligned) and their absmax2 (one value: 4 | blocksize2, so the four codes share it)
+                const int64_t ai = am4_src_row * wp.nblk + 4 * b;
+                auto g = (const __attribute__((address_space(1))) void *)(wp.am.i8 + ai);
+                auto l = (__attribute__((address_space(3))) void *)(smem + P_AM4 + (int)(blk & 1) * 2048 + wave * 128);
+                __builtin_amdgcn_global_load_lds(g, l, 4, 0, 0);
+                auto g2 = (const __attribute__((address_space(1))) void *)(wp.am.am2 + (ai >> wp.bs2_shift));
+                auto l2 = (__attribute__((address_space(3))) void *)(smem + P_AM4 + (int)(blk & 1) * 2048 + 1024 + wave * 128);
+                __builtin_amdgcn_global_load_lds(g2, l2, 4, 0, 0);
+            }
         }
     };
     // raw registers of the tile being decoded, by tile parity
@@ -486,10 +498,17 @@ __global__ __launch_bounds__(512, 2) void k_gemm256p(const T *__restrict__ X, ty
         constexpr int P = decltype(pp)::value;
         const char *base = smem + rs * RAW_BYTES;
         rw[P] = *reinterpret_cast<const u32x4 *>(base + raw_lane);
-        if constexpr (AM4) {
+        if constexpr (AM4 && !NESTED) {
             const int64_t t = k0 >> 6;  // (clamped) tile index
             ram[P] = *reinterpret_cast<const float *>(smem + P_AM4 + (int)((t >> 2) & 1) * 4096 + wave * 512 +
                                                       (b_row - 32 * wave) * 16 + (int)(t & 3) * 4);
+        } else if constexpr (AM4) {
+            const int64_t t = k0 >> 6;
+            const char *slot = smem + P_AM4 + (int)((t >> 2) & 1) * 2048 + wave * 128 + (b_row - 32 * wave) * 4;
+            const uint32_t word = *reinterpret_cast<const uint32_t *>(slot);
+            const float q = (float)(int)(int8_t)(word >> (8 * (int)(t & 3)));
+            const float a2 = *reinterpret_cast<const float *>(slot + 1024);
+            ram[P] = q * (a2 / 127.0f);  // dequantize_blockwise arithmetic (functional.py:592-594)
         } else if constexpr (!NESTED) {
             ram[P] = *reinterpret_cast<const float *>(base + raw_am);
         } else {
@@ -733,7 +752,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm256p(const T *__restrict__ X, ty
         __builtin_amdgcn_sched_barrier(0);
         stamp();
         // all but what this group just issued has landed: A(j+1), raw(j+2) (and older absmax blocks)
-        if constexpr (AM4) { if (am_now) { MBNB_VMCNT(2); } else { MBNB_VMCNT(1); } }
+        if constexpr (AM4) { if (am_now) { if constexpr (NESTED) MBNB_VMCNT(3); else MBNB_VMCNT(2); } else { MBNB_VMCNT(1); } }
         else if constexpr (NESTED) MBNB_VMCNT(3); else MBNB_VMCNT(2);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // own decode writes + fragment reads done
         __builtin_amdgcn_s_barrier();                         // stage Nn complete, stage C free
@@ -1486,7 +1505,8 @@ __global__ __launch_bounds__(512, 2) void k_gemm256pp(const T *__restrict__ X, t
 }
 
 template <bool NESTED> constexpr int gemm256p_lds_bytes() {
-    return P_RAW + 2 * (8192 + 2048 + (NESTED ? 2048 : 0)) + (NESTED ? 0 : 8192);  // + absmax-by-4 slots (AM4 variant, plain absmax only)
+    // stages + two raw slots + the absmax-by-4 slots of the AM4 variants (plain: 2 x 4 KiB, double-quantised: 2 x 2 KiB)
+    return P_RAW + 2 * (8192 + 2048 + (NESTED ? 2048 : 0)) + (NESTED ? 4096 : 8192);
 }
 
 }  // namespace mbnb

@@ -327,12 +327,17 @@ static int launch_matmul4(const void *A, int64_t M, int64_t K, const uint8_t *pa
                 KernT kern = use_valu ? k_gemm256v<T, NESTED>
                                       : (use_pp ? k_gemm256pp<T, NESTED>
                                                 : (no_blut ? k_gemm256p<T, NESTED> : k_gemm256p<T, NESTED, 0, false, true>));
+                static const bool no_am4 = getenv("MBNB_NO_AM4") != nullptr;  // debug A/B switch
                 if constexpr (!NESTED) {
-                    static const bool no_am4 = getenv("MBNB_NO_AM4") != nullptr;  // debug A/B switch
                     if (!no_am4 && !use_pp && blocksize == 64 && (K_weight % 256 == 0)) {
                         if (use_valu) kern = k_gemm256v<T, false, 0, true>;
                         else kern = no_blut ? k_gemm256p<T, false, 0, true> : k_gemm256p<T, false, 0, true, true>;
                     }
+                } else {
+                    // double-quantised absmax: four int8 codes (one aligned dword) + their shared absmax2 per four k-steps
+                    if (!no_am4 && !use_pp && !use_valu && blocksize == 64 && (K_weight % 256 == 0) && am.bs2 >= 4 &&
+                        (reinterpret_cast<uintptr_t>(am.i8) & 3) == 0)
+                        kern = no_blut ? k_gemm256p<T, true, 0, true> : k_gemm256p<T, true, 0, true, true>;
                 }
 #ifdef MBNB_ABLATION
                 if constexpr (std::is_same<T, bf16_t>::value && !NESTED) {

@@ -119,6 +119,36 @@ __global__ __launch_bounds__(512, 2) void probe(float *out, int roleA, int roleB
         }
         r = (float)accum + facc;
     }
+    else if (role >= 11 && role <= 14) {
+        // the decode writes of k_gemm256p with its real (swizzled) addresses: 4 x 16 B per lane and k-step;
+        // role 11: ds_write_b128, 12: 2 x ds_write_b64, 13: 4 x ds_write_b32, 14: ds_write_b128 to a linear (tid * 64) image
+        __shared__ __attribute__((aligned(16))) char img2[65536];
+        const int lane = threadIdx.x & 63, l32 = lane & 31;
+        const int b_row = 32 * wave + 16 * (lane >> 5) + 2 * (l32 & 7) + ((l32 >> 3) & 1);
+        const int b_half = l32 >> 4;
+        unsigned off[4];
+        for (int d = 0; d < 4; d++) {
+            const int chunk = 4 * b_half + d;
+            off[d] = role == 14 ? threadIdx.x * 64 + d * 16 : b_row * 128 + ((chunk ^ ((b_row >> 1) & 7)) << 4);
+        }
+        unsigned x = threadIdx.x;
+        for (int it = 0; it < n; it++) {
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                char *p = img2 + off[d] + (it & 1) * 32768;
+                if (role == 11 || role == 14) asm volatile("ds_write_b128 %0, %1" ::"v"((unsigned)(size_t)p), "v"(u32x4{x, x, x, x}) : "memory");
+                else if (role == 12) {
+                    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                    asm volatile("ds_write_b64 %0, %1\n\tds_write_b64 %0, %1 offset:8" ::"v"((unsigned)(size_t)p), "v"(u32x2{x, x}) : "memory");
+                } else {
+                    asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %0, %1 offset:4\n\tds_write_b32 %0, %1 offset:8\n\tds_write_b32 %0, %1 offset:12" ::"v"((unsigned)(size_t)p), "v"(x) : "memory");
+                }
+            }
+            x += it;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        r = (float)x;
+    }
     float s = r;
 #pragma unroll
     for (int i = 0; i < 8; i++) s += acc[i][0] + acc[i][7];
@@ -136,7 +166,8 @@ int main() {
         {5, 0, "MFMA+6xb128 prefetched | idle"}, {5, 5, "MFMA+6xb128 prefetched | same"},
         {6, 0, "MFMA+6xb128 in place | idle"}, {6, 6, "MFMA+6xb128 in place | same"},
         {7, 7, "LDS k-step mix (all 8 waves)"}, {8, 8, "  only 24 x ds_read_b128"}, {9, 9, "  only 32 x ds_read_b32 table"},
-        {10, 10, "  only 4 x ds_write_b128"}};
+        {10, 10, "  only 4 x ds_write_b128"}, {11, 11, "4 x ds_write_b128 real swizzle"}, {12, 12, "8 x ds_write_b64 real swizzle"},
+        {13, 13, "16 x ds_write_b32 real swizzle"}, {14, 14, "4 x ds_write_b128 linear"}, {11, 0, "4 x ds_write_b128 real, 4 waves"}};
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     for (auto &m : modes) {
