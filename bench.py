@@ -40,6 +40,7 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--no-empirical", action="store_true", help="skip the vendor-BLAS / copy-bandwidth context figures")
     ap.add_argument("--warmup", type=int, default=100)  # ~13 ms: the GPU clock needs a few ms of load to ramp
     ap.add_argument("--workload", default="nf4_m4096",
                     choices=["nf4_m4096", "nf4dq_ffn", "int8_4096", "nf4_m1"],
@@ -284,6 +285,26 @@ def main():
                            "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                         "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None}}
             del layers
+        if not args.no_empirical:
+            # Empirical ceilings of this box next to the vendor peaks: the vendor BLAS on the same
+            # 4096^3 bf16 problem with the weight already dequantised (torch.matmul -> hipBLASLt/rocBLAS; context
+            # only, not part of the product) and a 1 GiB device-to-device copy.
+            try:
+                Wd = bnb.dequantize_4bit(packed, state)
+                torch.matmul(X, Wd.t())
+                blas_ms = min(event_time_ms(lambda: torch.matmul(X, Wd.t()), 50) for _ in range(3))
+                del Wd
+                src = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+                dst = torch.empty_like(src)
+                dst.copy_(src)
+                copy_ms = min(event_time_ms(lambda: dst.copy_(src), 10) for _ in range(3))
+                del src, dst
+                out["roofline"]["empirical"] = {
+                    "vendor_blas_bf16_same_shape_tflops": round(2.0 * M * N * K / (blas_ms * 1e-3) / 1e12, 1),
+                    "vendor_blas_us": round(blas_ms * 1e3, 1),
+                    "dtod_copy_gbs_read_plus_write": round(2.0 * (1 << 30) / (copy_ms * 1e-3) / 1e9, 0)}
+            except Exception as e:  # context only: never fails the bench
+                out["roofline"]["empirical"] = {"error": str(e)[:200]}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, M, N, K, 64, compress, dt)
     if rank == 0 and wl == "nf4_m4096":
