@@ -148,6 +148,40 @@ int mbnb_matmul_int8(const int8_t *A, const int8_t *B, const float *A_scales,
 int mbnb_linear_int8(const void *X, int dtype, int64_t M, int64_t K, const int8_t *W,
                      const float *W_scales, int64_t N, const void *bias, void *out, void *stream);
 
+/* ---------------------------------------------------------------------------
+ * embedding_4bit — replaces `_C.embedding_4bit_nf4` / `_C.embedding_4bit_fp4` (host mm:2309-2388, kernels
+ * mm:1213-1275, bindings :2765-2770) with the numerics of Embedding4bit.forward's Python path
+ * (nn/embedding.py:83-138): out[t, :] = dequantize(row indices[t]) = code[nibble] * absmax[row, k / blocksize]
+ * in f32, rounded to `out_dtype`; rows equal to padding_idx (when has_padding) are zeros (:133-136).
+ *   weight_packed u8 [num_embeddings, embedding_dim/2], weight_absmax f32 [num_embeddings, ceil(dim/blocksize)],
+ *   indices int64 [n_indices] (the reference casts to int32; int64 is torch's native index type), out [n_indices, dim].
+ * Indices must lie in [0, num_embeddings): out-of-range rows are written as zeros (the reference raises on the host).
+ * ------------------------------------------------------------------------- */
+int mbnb_embedding_4bit(const int64_t *indices, int64_t n_indices, const uint8_t *weight_packed,
+                        const float *weight_absmax, int64_t num_embeddings, int64_t embedding_dim, int blocksize,
+                        int quant_type, int has_padding, int64_t padding_idx, int out_dtype, void *out, void *stream);
+
+/* embedding_8bit — replaces `_C.embedding_8bit` (host mm:2390-2427, kernel mm:1277-1294) with the numerics of
+ * Embedding8bit.forward's Python path (nn/embedding.py:255-268), arithmetic in `out_dtype` T:
+ *   out[t, k] = RNE_T( float(W[row, k]) * float(RNE_T(scales[row] / 127)) ),  zeros for padding rows. */
+int mbnb_embedding_8bit(const int64_t *indices, int64_t n_indices, const int8_t *weight_int8, const float *weight_scales,
+                        int64_t num_embeddings, int64_t embedding_dim, int has_padding, int64_t padding_idx,
+                        int out_dtype, void *out, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * outlier_linear — OutlierAwareLinear.forward (nn/outlier_aware.py:84-146; the reference has no native binding
+ * for it, the module is the boundary).  X [M,K], outlier_w [N, n_outliers], bias [N], out [M,N] in `dtype`:
+ *   q, s   = quantize_rowwise(X with the outlier columns removed)                       (:127-131)
+ *   main   = int32(q . W_i8[N,K]^T) * (s[m]/127) * (W_scales[n]/127)  rounded to dtype  (:133-138, on the int8 MFMA;
+ *            the reference multiplies dtype-rounded dequantised operands instead: <= 4e-4 (f16) / 1.3e-3 (bf16) rel.)
+ *   out    = RNE(RNE(main + RNE(X[:, outlier_idx] . outlier_w^T)) + bias)               (:141-143, :110-111)
+ * n_outliers may be 0 (pure INT8 path, :100-105).  `workspace` must hold mbnb_outlier_linear_workspace_bytes(M, K).
+ * ------------------------------------------------------------------------- */
+int64_t mbnb_outlier_linear_workspace_bytes(int64_t M, int64_t K);
+int mbnb_outlier_linear(const void *X, int dtype, int64_t M, int64_t K, const int8_t *W, const float *W_scales,
+                        int64_t N, const int64_t *outlier_idx, int64_t n_outliers, const void *outlier_w,
+                        const void *bias, void *out, void *workspace, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -18,9 +18,10 @@ from .functional import (
     quantize_fp4, dequantize_fp4, matmul_fp4, FP4_CODEBOOK, create_fp4_map,
     quantize_blockwise, dequantize_blockwise,
     quantize_rowwise, dequantize_rowwise, matmul_int8, linear_int8,
-    double_quant, dequant_absmax,
+    double_quant, dequant_absmax, embedding_4bit, embedding_8bit, outlier_linear,
 )
-from .nn import Linear4bit, Linear8bit, Params4bit
+from .nn import (Linear4bit, Linear8bit, Params4bit, Embedding4bit, Embedding8bit, EmbeddingNF4, EmbeddingFP4,
+                 OutlierAwareLinear)
 from .integration import (
     BitsAndBytesConfig, quantize_model, replace_linear_with_4bit, replace_linear_with_8bit, get_memory_footprint,
 )
@@ -46,6 +47,7 @@ __all__ = [
     'quantize_blockwise', 'dequantize_blockwise',
     'quantize_rowwise', 'dequantize_rowwise', 'matmul_int8', 'linear_int8',
     'double_quant', 'dequant_absmax',
-    'Linear4bit', 'Linear8bit', 'Params4bit',
+    'Linear4bit', 'Linear8bit', 'Params4bit', 'Embedding4bit', 'Embedding8bit', 'EmbeddingNF4', 'EmbeddingFP4',
+    'OutlierAwareLinear', 'embedding_4bit', 'embedding_8bit', 'outlier_linear',
     'BitsAndBytesConfig', 'quantize_model', 'replace_linear_with_4bit', 'replace_linear_with_8bit', 'get_memory_footprint',
 ]

@@ -53,6 +53,13 @@ _SIGNATURES = {
                                  c_void_p, c_void_p, c_void_p]),
     "mbnb_linear_int8": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
                                  c_void_p, c_void_p]),
+    "mbnb_embedding_4bit": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int,
+                                    c_int64, c_int, c_void_p, c_void_p]),
+    "mbnb_embedding_8bit": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int64, c_int,
+                                    c_void_p, c_void_p]),
+    "mbnb_outlier_linear_workspace_bytes": (c_int64, [c_int64, c_int64]),
+    "mbnb_outlier_linear": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -39,6 +39,9 @@ int double_quant_dispatch(const void *, int, int64_t, int64_t, int8_t *, int8_t 
 int matmul_4bit_dispatch(const void *, int64_t, int64_t, const uint8_t *, const AbsmaxView &, int64_t, int64_t, int, int, int, const void *, int, void *, hipStream_t);
 int matmul_int8_dispatch(const int8_t *, const int8_t *, const float *, const float *, int64_t, int64_t, int64_t, int, void *, void *, hipStream_t);
 int linear_int8_dispatch(const void *, int, int64_t, int64_t, const int8_t *, const float *, int64_t, const void *, void *, hipStream_t);
+int embedding_4bit_dispatch(const int64_t *, int64_t, const uint8_t *, const float *, int64_t, int64_t, int, int, int, int64_t, int, void *, hipStream_t);
+int embedding_8bit_dispatch(const int64_t *, int64_t, const int8_t *, const float *, int64_t, int64_t, int, int64_t, int, void *, hipStream_t);
+int outlier_linear_dispatch(const void *, int, int64_t, int64_t, const int8_t *, const float *, int64_t, const int64_t *, int64_t, const void *, const void *, void *, void *, hipStream_t);
 
 static bool dtype_ok(int d) { return d == MBNB_F16 || d == MBNB_BF16 || d == MBNB_F32; }
 static bool qt_ok(int q) { return q == MBNB_NF4 || q == MBNB_FP4; }
@@ -189,6 +192,49 @@ int mbnb_linear_int8(const void *X, int dtype, int64_t M, int64_t K, const int8_
     if (M == 0 || N == 0) return MBNB_OK;
     if (!X || !W || !W_scales || !out) return fail(MBNB_ERR_ARG, "linear_int8: NULL pointer");
     return linear_int8_dispatch(X, dtype, M, K, W, W_scales, N, bias, out, static_cast<hipStream_t>(stream));
+}
+
+int mbnb_embedding_4bit(const int64_t *indices, int64_t n_indices, const uint8_t *weight_packed, const float *weight_absmax,
+                        int64_t num_embeddings, int64_t embedding_dim, int blocksize, int quant_type, int has_padding,
+                        int64_t padding_idx, int out_dtype, void *out, void *stream) {
+    if (!dtype_ok(out_dtype)) return fail(MBNB_ERR_ARG, "embedding_4bit: bad dtype");
+    if (!qt_ok(quant_type)) return fail(MBNB_ERR_ARG, "embedding_4bit: bad quant_type");
+    if (n_indices < 0 || num_embeddings <= 0 || embedding_dim <= 0 || blocksize <= 0)
+        return fail(MBNB_ERR_ARG, "embedding_4bit: bad size");
+    if (embedding_dim % 2 != 0) return fail(MBNB_ERR_ARG, "embedding_4bit: embedding_dim must be even");
+    if (n_indices == 0) return MBNB_OK;
+    if (!indices || !weight_packed || !weight_absmax || !out) return fail(MBNB_ERR_ARG, "embedding_4bit: NULL pointer");
+    return embedding_4bit_dispatch(indices, n_indices, weight_packed, weight_absmax, num_embeddings, embedding_dim,
+                                   blocksize, quant_type, has_padding, padding_idx, out_dtype, out,
+                                   static_cast<hipStream_t>(stream));
+}
+
+int mbnb_embedding_8bit(const int64_t *indices, int64_t n_indices, const int8_t *weight_int8, const float *weight_scales,
+                        int64_t num_embeddings, int64_t embedding_dim, int has_padding, int64_t padding_idx, int out_dtype,
+                        void *out, void *stream) {
+    if (!dtype_ok(out_dtype)) return fail(MBNB_ERR_ARG, "embedding_8bit: bad dtype");
+    if (n_indices < 0 || num_embeddings <= 0 || embedding_dim <= 0) return fail(MBNB_ERR_ARG, "embedding_8bit: bad size");
+    if (n_indices == 0) return MBNB_OK;
+    if (!indices || !weight_int8 || !weight_scales || !out) return fail(MBNB_ERR_ARG, "embedding_8bit: NULL pointer");
+    return embedding_8bit_dispatch(indices, n_indices, weight_int8, weight_scales, num_embeddings, embedding_dim,
+                                   has_padding, padding_idx, out_dtype, out, static_cast<hipStream_t>(stream));
+}
+
+int64_t mbnb_outlier_linear_workspace_bytes(int64_t M, int64_t K) {
+    if (M < 0 || K < 0) return 0;
+    return ((M * K + 255) & ~(int64_t)255) + ((4 * M + 255) & ~(int64_t)255) + ((K + 255) & ~(int64_t)255);
+}
+
+int mbnb_outlier_linear(const void *X, int dtype, int64_t M, int64_t K, const int8_t *W, const float *W_scales, int64_t N,
+                        const int64_t *outlier_idx, int64_t n_outliers, const void *outlier_w, const void *bias, void *out,
+                        void *workspace, void *stream) {
+    if (!dtype_ok(dtype)) return fail(MBNB_ERR_ARG, "outlier_linear: bad dtype");
+    if (M < 0 || N < 0 || K <= 0 || n_outliers < 0) return fail(MBNB_ERR_ARG, "outlier_linear: bad size");
+    if (M == 0 || N == 0) return MBNB_OK;
+    if (!X || !W || !W_scales || !out || !workspace) return fail(MBNB_ERR_ARG, "outlier_linear: NULL pointer");
+    if (n_outliers > 0 && (!outlier_idx || !outlier_w)) return fail(MBNB_ERR_ARG, "outlier_linear: outliers without index/weight buffers");
+    return outlier_linear_dispatch(X, dtype, M, K, W, W_scales, N, outlier_idx, n_outliers, outlier_w, bias, out, workspace,
+                                   static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -20,6 +20,13 @@ template <> struct ElemT<MBNB_F32> { using type = float; };
 template <typename T> __device__ __forceinline__ float to_f32(T v) { return (float)v; }
 // RNE conversions: plain casts lower to v_cvt_f16_f32 / v_cvt_pk_bf16_f32 on gfx950.
 template <typename T> __device__ __forceinline__ T from_f32(float v) { return (T)v; }
+// f32 -> f16 must round a value that already exists in f32: without the (empty) asm the compiler folds a preceding
+// multiply into v_fma_mixlo_f16, which rounds the exact product ONCE, where the reference rounds to f32 and then
+// to f16 (functional.py: `(code * absmax).to(dtype)`) -- 1 ulp apart on f16 ties (seen: 64 of 393 216 embedding values).
+template <> __device__ __forceinline__ f16_t from_f32<f16_t>(float v) {
+    asm("" : "+v"(v));
+    return (f16_t)v;
+}
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -36,6 +43,7 @@ typedef short s16x2 __attribute__((ext_vector_type(2)));
 // pack two f32 into one dword of two 16-bit values (RNE), element 0 in the low half
 template <typename T> __device__ __forceinline__ uint32_t pack2(float lo, float hi);
 template <> __device__ __forceinline__ uint32_t pack2<f16_t>(float lo, float hi) {
+    asm("" : "+v"(lo), "+v"(hi));  // no v_fma_mix*_f16 folding of the producing multiplies (see from_f32<f16_t>)
     f16x2 v = {(f16_t)lo, (f16_t)hi};
     return __builtin_bit_cast(uint32_t, v);
 }

@@ -290,22 +290,32 @@ __global__ __launch_bounds__(256) void k_matmul_i8_generic(const int8_t *__restr
     out[i] = from_f32<OutT>((float)acc * (sA[m] / 127.0f) * (sB[n] / 127.0f));
 }
 
-int matmul_int8_dispatch(const int8_t *A, const int8_t *B, const float *sA, const float *sB, int64_t M, int64_t N,
-                         int64_t K, int out_dtype, void *out, void *workspace, hipStream_t st) {
-    const bool fast = (K % 16 == 0) && workspace != nullptr &&
-                      ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(workspace)) & 15) == 0;
+// B already K-contiguous ([N, K]: Linear8bit / OutlierAwareLinear weights, or the transposed workspace of matmul_int8)
+template <typename OutT>
+__global__ __launch_bounds__(256) void k_matmul_i8_generic_nt(const int8_t *__restrict__ A, const int8_t *__restrict__ Bt,
+                                                             const float *__restrict__ sA, const float *__restrict__ sB,
+                                                             OutT *__restrict__ out, int64_t M, int64_t N, int64_t K) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * N) return;
+    const int64_t m = i / N, n = i % N;
+    int acc = 0;
+    for (int64_t k = 0; k < K; k++) acc += (int)A[m * K + k] * (int)Bt[n * K + k];
+    out[i] = from_f32<OutT>((float)acc * (sA[m] / 127.0f) * (sB[n] / 127.0f));
+}
+
+int matmul_int8_nt_dispatch(const int8_t *A, const int8_t *Bt, const float *sA, const float *sB, int64_t M, int64_t N,
+                            int64_t K, int out_dtype, void *out, hipStream_t st) {
+    const bool fast = (K % 16 == 0) && ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(Bt)) & 15) == 0;
     if (!fast) {
         const unsigned grid = (unsigned)((M * N + 255) / 256);
         switch (out_dtype) {
-            case MBNB_F16: hipLaunchKernelGGL(k_matmul_i8_generic<f16_t>, dim3(grid), dim3(256), 0, st, A, B, sA, sB, static_cast<f16_t *>(out), M, N, K); break;
-            case MBNB_BF16: hipLaunchKernelGGL(k_matmul_i8_generic<bf16_t>, dim3(grid), dim3(256), 0, st, A, B, sA, sB, static_cast<bf16_t *>(out), M, N, K); break;
-            default: hipLaunchKernelGGL(k_matmul_i8_generic<float>, dim3(grid), dim3(256), 0, st, A, B, sA, sB, static_cast<float *>(out), M, N, K); break;
+            case MBNB_F16: hipLaunchKernelGGL(k_matmul_i8_generic_nt<f16_t>, dim3(grid), dim3(256), 0, st, A, Bt, sA, sB, static_cast<f16_t *>(out), M, N, K); break;
+            case MBNB_BF16: hipLaunchKernelGGL(k_matmul_i8_generic_nt<bf16_t>, dim3(grid), dim3(256), 0, st, A, Bt, sA, sB, static_cast<bf16_t *>(out), M, N, K); break;
+            default: hipLaunchKernelGGL(k_matmul_i8_generic_nt<float>, dim3(grid), dim3(256), 0, st, A, Bt, sA, sB, static_cast<float *>(out), M, N, K); break;
         }
         set_kernel_name("i8_generic");
-        return check_launch("matmul_int8(generic)");
+        return check_launch("matmul_int8(generic nt)");
     }
-    int8_t *Bt = static_cast<int8_t *>(workspace);
-    hipLaunchKernelGGL(k_transpose_i8, dim3((unsigned)((N + 63) / 64), (unsigned)((K + 63) / 64)), dim3(256), 0, st, B, Bt, K, N);
     if ((K % 128 == 0) && ((M + 255) / 256) * ((N + 255) / 256) >= 96) {
         const int64_t tiles256 = ((M + 255) / 256) * ((N + 255) / 256);
         constexpr int lds256 = 4 * P_IMG;
@@ -350,6 +360,25 @@ int matmul_int8_dispatch(const int8_t *A, const int8_t *B, const float *sA, cons
 #undef MBNB_I8
     set_kernel_name("i8_mfma128");
     return check_launch("matmul_int8(mfma)");
+}
+
+int matmul_int8_dispatch(const int8_t *A, const int8_t *B, const float *sA, const float *sB, int64_t M, int64_t N,
+                         int64_t K, int out_dtype, void *out, void *workspace, hipStream_t st) {
+    const bool fast = (K % 16 == 0) && workspace != nullptr &&
+                      ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(workspace)) & 15) == 0;
+    if (!fast) {
+        const unsigned grid = (unsigned)((M * N + 255) / 256);
+        switch (out_dtype) {
+            case MBNB_F16: hipLaunchKernelGGL(k_matmul_i8_generic<f16_t>, dim3(grid), dim3(256), 0, st, A, B, sA, sB, static_cast<f16_t *>(out), M, N, K); break;
+            case MBNB_BF16: hipLaunchKernelGGL(k_matmul_i8_generic<bf16_t>, dim3(grid), dim3(256), 0, st, A, B, sA, sB, static_cast<bf16_t *>(out), M, N, K); break;
+            default: hipLaunchKernelGGL(k_matmul_i8_generic<float>, dim3(grid), dim3(256), 0, st, A, B, sA, sB, static_cast<float *>(out), M, N, K); break;
+        }
+        set_kernel_name("i8_generic");
+        return check_launch("matmul_int8(generic)");
+    }
+    int8_t *Bt = static_cast<int8_t *>(workspace);
+    hipLaunchKernelGGL(k_transpose_i8, dim3((unsigned)((N + 63) / 64), (unsigned)((K + 63) / 64)), dim3(256), 0, st, B, Bt, K, N);
+    return matmul_int8_nt_dispatch(A, Bt, sA, sB, M, N, K, out_dtype, out, st);
 }
 
 // ------------------------------------------------------------------ linear_int8 (W8A16)

@@ -568,6 +568,94 @@ def linear_int8(input: Tensor, weight_int8: Tensor, weight_scales: Tensor, bias:
     return out.reshape(*input.shape[:-1], N)
 
 
+# ============================================================================= quantized embedding lookups
+def embedding_4bit(input: Tensor, weight_packed: Tensor, weight_absmax: Tensor, embedding_dim: int,
+                   blocksize: int = 64, quant_type: str = 'nf4', padding_idx: Optional[int] = None,
+                   dtype: torch.dtype = torch.float16) -> Tensor:
+    """
+    Gather + dequantize rows of a 4-bit embedding table in one kernel: the forward of Embedding4bit
+    (reference: nn/embedding.py:83-138; native bindings `_C.embedding_4bit_nf4/_fp4`, mm:2309-2388).
+    `weight_packed` u8 [num, dim/2], `weight_absmax` f32 [num, ceil(dim/blocksize)]; returns
+    ``input.shape + [embedding_dim]`` in `dtype`, rows equal to `padding_idx` zeroed.  Bit-exact against the
+    reference's Python path.  Indices are not range-checked on the host (no device synchronisation);
+    out-of-range rows come back as zeros.
+    """
+    _check_device(weight_packed, "embedding_4bit")
+    if quant_type not in _native.QUANT_CODE:
+        raise ValueError(f"quant_type must be 'nf4' or 'fp4', got {quant_type}")
+    dev = weight_packed.device
+    idx = input.to(device=dev, dtype=torch.int64).reshape(-1).contiguous()
+    num = weight_packed.shape[0]
+    out = torch.empty(idx.numel(), embedding_dim, dtype=dtype, device=dev)
+    wp = weight_packed.contiguous()
+    wa = weight_absmax.to(device=dev, dtype=torch.float32).contiguous()
+    with torch.cuda.device(dev):
+        check(_native.lib().mbnb_embedding_4bit(ptr(idx), idx.numel(), ptr(wp), ptr(wa), num, int(embedding_dim),
+                                                int(blocksize), _native.QUANT_CODE[quant_type], int(padding_idx is not None),
+                                                int(padding_idx) if padding_idx is not None else 0,
+                                                dtype_code(dtype, "embedding_4bit"), ptr(out), stream_ptr(dev)),
+              "embedding_4bit")
+    return out.reshape(*input.shape, embedding_dim)
+
+
+def embedding_8bit(input: Tensor, weight_int8: Tensor, weight_scales: Tensor, padding_idx: Optional[int] = None,
+                   dtype: torch.dtype = torch.float16) -> Tensor:
+    """
+    Gather + dequantize rows of an int8 embedding table: the forward of Embedding8bit
+    (reference: nn/embedding.py:255-268; native binding `_C.embedding_8bit`, mm:2390-2427).  Bit-exact against the
+    reference's Python path: ``q.to(dtype) * (scale / 127.0).to(dtype)``.
+    """
+    _check_device(weight_int8, "embedding_8bit")
+    dev = weight_int8.device
+    idx = input.to(device=dev, dtype=torch.int64).reshape(-1).contiguous()
+    num, dim = weight_int8.shape
+    out = torch.empty(idx.numel(), dim, dtype=dtype, device=dev)
+    w = weight_int8.contiguous()
+    s = weight_scales.to(device=dev, dtype=torch.float32).contiguous()
+    with torch.cuda.device(dev):
+        check(_native.lib().mbnb_embedding_8bit(ptr(idx), idx.numel(), ptr(w), ptr(s), num, dim,
+                                                int(padding_idx is not None),
+                                                int(padding_idx) if padding_idx is not None else 0,
+                                                dtype_code(dtype, "embedding_8bit"), ptr(out), stream_ptr(dev)),
+              "embedding_8bit")
+    return out.reshape(*input.shape, dim)
+
+
+# ============================================================================= outlier-aware INT8 linear
+def outlier_linear(input: Tensor, weight_int8: Tensor, weight_scales: Tensor, outlier_indices: Tensor,
+                   outlier_weights: Tensor, bias: Optional[Tensor] = None,
+                   dtype: Optional[torch.dtype] = None) -> Tensor:
+    """
+    The forward of OutlierAwareLinear (reference: nn/outlier_aware.py:84-146): row-wise INT8 quantisation of the
+    non-outlier input columns, int8 x int8 contraction on the MFMA, the outlier columns in `dtype`, bias.
+    The reference multiplies dtype-rounded dequantised operands; the exact integer contraction used here differs
+    from it by <= 4e-4 (fp16) / 1.3e-3 (bf16) relative (Frobenius).
+    """
+    _check_device(input, "outlier_linear")
+    _check_device(weight_int8, "outlier_linear")
+    if dtype is None:
+        dtype = input.dtype
+    dcode = dtype_code(dtype, "outlier_linear")
+    N, K = weight_int8.shape
+    if input.shape[-1] != K:
+        raise RuntimeError(f"outlier_linear: input width {input.shape[-1]} does not match weight {tuple(weight_int8.shape)}")
+    dev = input.device
+    x = input.reshape(-1, K).to(dtype).contiguous()
+    M = x.shape[0]
+    w = weight_int8.contiguous()
+    s = weight_scales.to(device=dev, dtype=torch.float32).contiguous()
+    n_out = int(outlier_indices.numel())
+    oi = outlier_indices.to(device=dev, dtype=torch.int64).contiguous() if n_out else None
+    ow = outlier_weights.to(device=dev, dtype=dtype).contiguous() if n_out else None
+    b = None if bias is None else bias.to(device=dev, dtype=dtype).contiguous()
+    out = torch.empty(M, N, dtype=dtype, device=dev)
+    ws = torch.empty(int(_native.lib().mbnb_outlier_linear_workspace_bytes(M, K)), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        check(_native.lib().mbnb_outlier_linear(ptr(x), dcode, M, K, ptr(w), ptr(s), N, ptr(oi), n_out, ptr(ow), ptr(b),
+                                                ptr(out), ptr(ws), stream_ptr(dev)), "outlier_linear")
+    return out.reshape(*input.shape[:-1], N)
+
+
 # ============================================================================= double quant (LLM.int8 stats)
 def double_quant(
     A: Tensor,

@@ -43,7 +43,8 @@ def lib():
         _lib = ctypes.CDLL(_LIB_PATH)
         for name in ("orc_quantize_4bit", "orc_dequantize_4bit", "orc_quantize_blockwise",
                      "orc_dequantize_blockwise", "orc_quantize_rowwise", "orc_dequantize_rowwise",
-                     "orc_double_quant", "orc_matmul_4bit", "orc_matmul_int8", "orc_linear_int8"):
+                     "orc_double_quant", "orc_matmul_4bit", "orc_matmul_int8", "orc_linear_int8",
+                     "orc_embedding_4bit", "orc_embedding_8bit", "orc_outlier_linear"):
             getattr(_lib, name).restype = ctypes.c_int
     return _lib
 
@@ -235,4 +236,50 @@ def linear_int8(x: torch.Tensor, weight_int8: torch.Tensor, weight_scales: torch
     _chk(lib().orc_linear_int8(_p(x2), _DT[x.dtype], _i64(M), _i64(K), _p(weight_int8.contiguous()),
                                _p(weight_scales.float().contiguous()), _i64(N), _p(b), _p(out)),
          "linear_int8")
+    return out.reshape(*lead, N)
+
+
+def embedding_4bit(input: torch.Tensor, weight_packed: torch.Tensor, weight_absmax: torch.Tensor,
+                   embedding_dim: int, blocksize: int = 64, quant_type: str = "nf4",
+                   padding_idx: Optional[int] = None, dtype: torch.dtype = torch.float16) -> torch.Tensor:
+    """Embedding4bit.forward, nn/embedding.py:83-138 (Python path)."""
+    idx = input.reshape(-1).to(torch.int64).contiguous()
+    out = torch.empty(idx.numel(), embedding_dim, dtype=dtype)
+    _chk(lib().orc_embedding_4bit(_p(idx), _i64(idx.numel()), _p(weight_packed.contiguous()),
+                                  _p(weight_absmax.float().contiguous()), _i64(weight_packed.shape[0]),
+                                  _i64(embedding_dim), int(blocksize), _QT[quant_type],
+                                  int(padding_idx is not None), _i64(padding_idx if padding_idx is not None else 0),
+                                  _DT[dtype], _p(out)), "embedding_4bit")
+    return out.reshape(*input.shape, embedding_dim)
+
+
+def embedding_8bit(input: torch.Tensor, weight_int8: torch.Tensor, weight_scales: torch.Tensor,
+                   padding_idx: Optional[int] = None, dtype: torch.dtype = torch.float16) -> torch.Tensor:
+    """Embedding8bit.forward, nn/embedding.py:255-268 (Python path)."""
+    idx = input.reshape(-1).to(torch.int64).contiguous()
+    dim = weight_int8.shape[1]
+    out = torch.empty(idx.numel(), dim, dtype=dtype)
+    _chk(lib().orc_embedding_8bit(_p(idx), _i64(idx.numel()), _p(weight_int8.contiguous()),
+                                  _p(weight_scales.float().contiguous()), _i64(weight_int8.shape[0]), _i64(dim),
+                                  int(padding_idx is not None), _i64(padding_idx if padding_idx is not None else 0),
+                                  _DT[dtype], _p(out)), "embedding_8bit")
+    return out.reshape(*input.shape, dim)
+
+
+def outlier_linear(x: torch.Tensor, weight_int8: torch.Tensor, weight_scales: torch.Tensor,
+                   outlier_indices: torch.Tensor, outlier_weights: torch.Tensor,
+                   bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """OutlierAwareLinear.forward, nn/outlier_aware.py:84-146; x, outlier_weights, bias in the compute dtype."""
+    lead = x.shape[:-1]
+    x2 = x.reshape(-1, x.shape[-1]).contiguous()
+    M, K = x2.shape
+    N = weight_int8.shape[0]
+    oi = outlier_indices.to(torch.int64).contiguous()
+    ow = outlier_weights.to(x.dtype).contiguous()
+    b = None if bias is None else bias.to(x.dtype).contiguous()
+    out = torch.empty(M, N, dtype=x.dtype)
+    _chk(lib().orc_outlier_linear(_p(x2), _DT[x.dtype], _i64(M), _i64(K), _p(weight_int8.contiguous()),
+                                  _p(weight_scales.float().contiguous()), _i64(N),
+                                  _p(oi) if oi.numel() else None, _i64(oi.numel()),
+                                  _p(ow) if oi.numel() else None, _p(b), _p(out)), "outlier_linear")
     return out.reshape(*lead, N)

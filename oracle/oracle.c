@@ -444,6 +444,120 @@ int orc_linear_int8(const void *X, int dtype, int64_t M, int64_t K, const int8_t
     return 0;
 }
 
+/* ---------------------------------------------------------------------------
+ * Embedding4bit.forward — nn/embedding.py:83-138 (the Python path):
+ *   row r = input[t]; QuantState(absmax[r], shape [dim], blocksize, dtype) -> dequantize_nf4/fp4(packed[r])
+ *   = code[nibble] * absmax[r, k / blocksize] in f32 -> .to(dtype)   (functional.py:388-416, low nibble = even k)
+ *   rows equal to padding_idx are masked to 0.0 (:133-136).  has_padding = 0: no masking.
+ * weight_packed [num, dim/2] u8, weight_absmax [num, ceil(dim/blocksize)] f32 (:70-77).
+ * ------------------------------------------------------------------------- */
+int orc_embedding_4bit(const int64_t *idx, int64_t n_idx, const uint8_t *packed, const float *absmax,
+                       int64_t num_embeddings, int64_t dim, int blocksize, int quant_type,
+                       int has_padding, int64_t padding_idx, int out_dtype, void *out) {
+    const float *code = code_table(quant_type);
+    const int64_t nblk = (dim + blocksize - 1) / blocksize;
+    for (int64_t t = 0; t < n_idx; t++)
+        if (idx[t] < 0 || idx[t] >= num_embeddings) return -1;
+#pragma omp parallel for schedule(static)
+    for (int64_t t = 0; t < n_idx; t++) {
+        const int64_t r = idx[t];
+        const int pad = has_padding && r == padding_idx;
+        for (int64_t k = 0; k < dim; k++) {
+            const uint8_t b = packed[r * (dim / 2) + (k >> 1)];
+            const int nib = (k & 1) ? (b >> 4) : (b & 15);
+            const float v = code[nib] * absmax[r * nblk + k / blocksize];
+            store_elem(out, out_dtype, t * dim + k, pad ? 0.0f : v);
+        }
+    }
+    return 0;
+}
+
+/* ---------------------------------------------------------------------------
+ * Embedding8bit.forward — nn/embedding.py:255-268 (the Python path), arithmetic in `dtype`:
+ *   weight_int8[input].to(dtype) * (scales[input].unsqueeze(-1) / 127.0).to(dtype)
+ *   i.e. the f32 quotient is rounded to dtype first, then one dtype multiply (computed in f32, rounded once).
+ * ------------------------------------------------------------------------- */
+int orc_embedding_8bit(const int64_t *idx, int64_t n_idx, const int8_t *W, const float *scales,
+                       int64_t num_embeddings, int64_t dim, int has_padding, int64_t padding_idx,
+                       int out_dtype, void *out) {
+    for (int64_t t = 0; t < n_idx; t++)
+        if (idx[t] < 0 || idx[t] >= num_embeddings) return -1;
+#pragma omp parallel for schedule(static)
+    for (int64_t t = 0; t < n_idx; t++) {
+        const int64_t r = idx[t];
+        const int pad = has_padding && r == padding_idx;
+        const float s = round_to(out_dtype, scales[r] / 127.0f);
+        for (int64_t k = 0; k < dim; k++)
+            store_elem(out, out_dtype, t * dim + k, pad ? 0.0f : (float)W[r * dim + k] * s);
+    }
+    return 0;
+}
+
+/* ---------------------------------------------------------------------------
+ * OutlierAwareLinear.forward — nn/outlier_aware.py:84-146, arithmetic in `dtype` (compute_dtype):
+ *   non-outlier columns of x: quantize_rowwise (functional.py:607-625) over those columns only  (:127-131)
+ *   x_fp = q.to(dtype) * (x_scales/127).to(dtype);  w_fp = W.to(dtype) * (w_scales/127).to(dtype) (:135-136)
+ *   output_main = mm(x_fp, w_fp.t())  (f32 accumulate, one rounding to dtype)                    (:138)
+ *   output_outlier = mm(x[:, outlier_idx].to(dtype), outlier_weights.t())                        (:141)
+ *   output = output_main + output_outlier  (dtype add; absent when there are no outliers, :100-105)
+ *   output = output + bias                 (dtype add, :110-111)
+ * W [N,K] int8; outlier_w [N, n_out] in dtype; x, bias in dtype.
+ * ------------------------------------------------------------------------- */
+int orc_outlier_linear(const void *X, int dtype, int64_t M, int64_t K, const int8_t *W,
+                       const float *w_scales, int64_t N, const int64_t *outlier_idx, int64_t n_out,
+                       const void *outlier_w, const void *bias, void *out) {
+    uint8_t *is_out = (uint8_t *)calloc((size_t)K, 1);
+    float *Af = (float *)malloc(sizeof(float) * (size_t)(M * K));
+    float *Wf = (float *)malloc(sizeof(float) * (size_t)(N * K));
+    float *Cf = (float *)malloc(sizeof(float) * (size_t)(M * N));
+    if (!is_out || !Af || !Wf || !Cf) { free(is_out); free(Af); free(Wf); free(Cf); return -2; }
+    for (int64_t j = 0; j < n_out; j++) {
+        if (outlier_idx[j] < 0 || outlier_idx[j] >= K) { free(is_out); free(Af); free(Wf); free(Cf); return -1; }
+        is_out[outlier_idx[j]] = 1;
+    }
+#pragma omp parallel for schedule(static)
+    for (int64_t m = 0; m < M; m++) {
+        float am = 0.0f;
+        for (int64_t k = 0; k < K; k++) {
+            if (is_out[k]) continue;
+            float v = fabsf(load_elem(X, dtype, m * K + k));
+            if (v > am) am = v;
+        }
+        if (am < 1e-8f) am = 1e-8f;
+        const float r = rscale127(am);
+        const float s = round_to(dtype, am / 127.0f);
+        for (int64_t k = 0; k < K; k++) {
+            if (is_out[k]) { Af[m * K + k] = 0.0f; continue; }   /* column not part of x_main */
+            float q = rintf(load_elem(X, dtype, m * K + k) * r);
+            if (q < -127.0f) q = -127.0f;
+            if (q > 127.0f) q = 127.0f;
+            Af[m * K + k] = round_to(dtype, q * s);
+        }
+    }
+#pragma omp parallel for schedule(static)
+    for (int64_t n = 0; n < N; n++) {
+        const float s = round_to(dtype, w_scales[n] / 127.0f);
+        for (int64_t k = 0; k < K; k++)
+            Wf[n * K + k] = is_out[k] ? 0.0f : round_to(dtype, (float)W[n * K + k] * s);
+    }
+    sgemm_nt(Af, Wf, NULL, Cf, M, N, K);
+#pragma omp parallel for schedule(static)
+    for (int64_t m = 0; m < M; m++)
+        for (int64_t n = 0; n < N; n++) {
+            float v = round_to(dtype, Cf[m * N + n]);
+            if (n_out > 0) {
+                float o = 0.0f;
+                for (int64_t j = 0; j < n_out; j++)
+                    o += load_elem(X, dtype, m * K + outlier_idx[j]) * load_elem(outlier_w, dtype, n * n_out + j);
+                v = round_to(dtype, v + round_to(dtype, o));
+            }
+            if (bias) v = round_to(dtype, v + load_elem(bias, dtype, n));
+            store_elem(out, dtype, m * N + n, v);
+        }
+    free(is_out); free(Af); free(Wf); free(Cf);
+    return 0;
+}
+
 int orc_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -1,0 +1,149 @@
+"""
+GPU parity for the SURVEY §8f rank-3 rows: Embedding4bit / Embedding8bit / OutlierAwareLinear through the C ABI
+(mbnb_embedding_4bit, mbnb_embedding_8bit, mbnb_outlier_linear) against (a) the reference's outputs
+(tests/golden/g6_nn.npz) and (b) the CPU oracle on larger seeded inputs.  Embeddings: bit-exact.
+OutlierAwareLinear: Frobenius rel-err; the kernel contracts exact integers on the int8 MFMA where the reference
+multiplies dtype-rounded dequantised operands, so its gate is 1e-3 (fp16) / 4e-3 (bf16), hard tolerance 1e-2.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+import mps_bitsandbytes_amd as bnb
+from mps_bitsandbytes_amd import _native, synthetic
+from tests.goldenio import DT, HERE, bits_equal, from_bits, n_mismatch, rel_fro
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+OA_TOL = {torch.float16: 1e-3, torch.bfloat16: 4e-3}
+
+
+@pytest.fixture(scope="module")
+def g6():
+    with open(os.path.join(HERE, "manifest_nn.json")) as f:
+        cases = json.load(f)["g6"]
+    return cases, np.load(os.path.join(HERE, "g6_nn.npz"))
+
+
+def _emb(num, dim, dt, pad, seed):
+    e = torch.nn.Embedding(num, dim, padding_idx=pad)
+    with torch.no_grad():
+        e.weight.copy_(synthetic.normal((num, dim), torch.float32, seed=seed, std=0.5))
+    return e.to(dt)
+
+
+def test_embedding4bit_golden_bit_exact(g6):
+    cases, z = g6
+    for c in [c for c in cases if c["kind"] == "embedding4bit"]:
+        i, dt = c["id"], DT[c["dtype"]]
+        emb = torch.nn.Embedding(c["num"], c["dim"], padding_idx=c["padding_idx"]).to(dt)
+        emb.weight.data.copy_(from_bits(z[f"e4{i}_W"], dt))
+        e4 = bnb.Embedding4bit.from_embedding(emb.to(DEV), quant_type=c["quant_type"], blocksize=c["blocksize"])
+        assert sorted(e4.state_dict().keys()) == c["state_keys"]
+        assert bits_equal(e4.weight_packed.cpu(), from_bits(z[f"e4{i}_packed"]))
+        assert bits_equal(e4.weight_absmax.cpu(), from_bits(z[f"e4{i}_absmax"]))
+        idx = torch.from_numpy(z[f"e4{i}_idx"])
+        y = e4(idx.to(DEV))
+        assert y.dtype == dt and tuple(y.shape) == tuple(idx.shape) + (c["dim"],)
+        assert n_mismatch(y.cpu(), from_bits(z[f"e4{i}_y"], dt).reshape(y.shape)) == 0, c
+        assert _native.last_kernel() == "embedding4"
+        if c["padding_idx"] is not None:
+            assert float(y[0, 0].abs().max()) == 0.0
+
+
+def test_embedding8bit_golden_bit_exact(g6):
+    cases, z = g6
+    for c in [c for c in cases if c["kind"] == "embedding8bit"]:
+        i, dt = c["id"], DT[c["dtype"]]
+        emb = torch.nn.Embedding(c["num"], c["dim"], padding_idx=c["padding_idx"]).to(dt)
+        emb.weight.data.copy_(from_bits(z[f"e8{i}_W"], dt))
+        e8 = bnb.Embedding8bit.from_embedding(emb.to(DEV))
+        assert sorted(e8.state_dict().keys()) == c["state_keys"]
+        assert bits_equal(e8.weight_int8.cpu(), from_bits(z[f"e8{i}_q"])) and bits_equal(e8.weight_scales.cpu(), from_bits(z[f"e8{i}_s"]))
+        idx = torch.from_numpy(z[f"e8{i}_idx"])
+        y = e8(idx.to(DEV))
+        assert n_mismatch(y.cpu(), from_bits(z[f"e8{i}_y"], dt).reshape(y.shape)) == 0, c
+        assert _native.last_kernel() == "embedding8"
+
+
+@pytest.mark.parametrize("num,dim,qt,bs,dt,pad", [(32000, 4096, "nf4", 64, torch.bfloat16, 0), (5000, 1024, "fp4", 128, torch.float16, None),
+                                                   (300, 96, "nf4", 32, torch.float16, 7), (128, 4096, "nf4", 64, torch.float32, None)])
+def test_embedding4bit_vs_oracle(num, dim, qt, bs, dt, pad):
+    """LLM-sized table (32000 x 4096), ragged dims (96: scalar tail path), f32 output; 4096 looked-up rows with repeats."""
+    src = dt if dt != torch.float32 else torch.float16
+    W = synthetic.normal((num, dim), src, seed=801, std=0.5)
+    packed, absmax, _ = oracle.quantize_4bit(W, blocksize=bs, quant_type=qt)
+    packed, absmax = packed.reshape(num, dim // 2), absmax.reshape(num, -1)
+    idx = torch.from_numpy((synthetic.uniform_u64(4096, seed=802) % np.uint64(num)).astype(np.int64)).reshape(8, 512)
+    if pad is not None:
+        idx[3, 17] = pad
+    y = bnb.embedding_4bit(idx.to(DEV), packed.to(DEV), absmax.to(DEV), dim, bs, qt, pad, dt)
+    ref = oracle.embedding_4bit(idx, packed, absmax, dim, bs, qt, pad, dt)
+    assert n_mismatch(y.cpu(), ref) == 0
+
+
+@pytest.mark.parametrize("num,dim,dt,pad", [(32000, 4096, torch.bfloat16, 1), (777, 70, torch.float16, None)])
+def test_embedding8bit_vs_oracle(num, dim, dt, pad):
+    W = synthetic.normal((num, dim), dt, seed=811, std=0.5)
+    q, s = oracle.quantize_rowwise(W)
+    idx = torch.from_numpy((synthetic.uniform_u64(2048, seed=812) % np.uint64(num)).astype(np.int64))
+    if pad is not None:
+        idx[5] = pad
+    y = bnb.embedding_8bit(idx.to(DEV), q.to(DEV), s.to(DEV), pad, dt)
+    assert n_mismatch(y.cpu(), oracle.embedding_8bit(idx, q, s, pad, dt)) == 0
+
+
+def test_embedding_out_of_range_rows_are_zero_and_module_validation():
+    e = bnb.Embedding8bit(10, 16, device=DEV)
+    y = e(torch.tensor([3, 10, -1], device=DEV))
+    assert float(y[1].abs().max()) == 0.0 and float(y[2].abs().max()) == 0.0
+    with pytest.raises(ValueError, match="embedding_dim must be even"):
+        bnb.Embedding4bit(10, 15)
+    with pytest.raises(ValueError, match="quant_type must be"):
+        bnb.Embedding4bit(10, 16, quant_type="int4")
+    assert isinstance(bnb.EmbeddingNF4(100, 64, device=DEV), bnb.Embedding4bit) and bnb.EmbeddingFP4(100, 64).quant_type == "fp4"
+
+
+def test_outlier_linear_golden(g6):
+    cases, z = g6
+    for c in [c for c in cases if c["kind"] == "outlier_linear"]:
+        i, dt = c["id"], DT[c["dtype"]]
+        lin = torch.nn.Linear(c["K"], c["N"], bias=c["bias"]).to(dt)
+        lin.weight.data.copy_(from_bits(z[f"oa{i}_W"], dt))
+        if c["bias"]:
+            lin.bias.data.copy_(from_bits(z[f"oa{i}_bias"], dt))
+        oa = bnb.OutlierAwareLinear.from_linear(lin.to(DEV), threshold=c["threshold"])
+        assert sorted(oa.state_dict().keys()) == c["state_keys"]
+        assert torch.equal(oa.outlier_indices.cpu(), torch.from_numpy(z[f"oa{i}_oidx"]))
+        assert bits_equal(oa.weight_int8.cpu(), from_bits(z[f"oa{i}_q"])) and bits_equal(oa.weight_scales.cpu(), from_bits(z[f"oa{i}_s"]))
+        assert bits_equal(oa.outlier_weights.cpu().contiguous(), from_bits(z[f"oa{i}_ow"], dt).reshape(c["N"], -1))
+        x = from_bits(z[f"oa{i}_x"], dt).reshape(*c["M"], c["K"])
+        y = oa(x.to(DEV))
+        ref = from_bits(z[f"oa{i}_y"], dt).reshape(*c["M"], c["N"])
+        assert y.shape == ref.shape and y.dtype == dt
+        assert rel_fro(y.cpu(), ref) <= OA_TOL[dt], (c, rel_fro(y.cpu(), ref))
+
+
+@pytest.mark.parametrize("M,K,N,dt,n_out,bias", [(512, 4096, 4096, torch.float16, 12, True), (300, 1024, 777, torch.bfloat16, 0, True),
+                                                  (64, 200, 96, torch.float16, 3, False), (2048, 4096, 4096, torch.bfloat16, 40, False)])
+def test_outlier_linear_vs_oracle(M, K, N, dt, n_out, bias):
+    """MFMA-sized shapes (256^2 and 128^2 int8 kernels), ragged K (generic kernel), with / without outliers and bias."""
+    W = synthetic.normal((N, K), torch.float32, seed=821, std=0.05)
+    oidx = torch.from_numpy(np.sort((synthetic.uniform_u64(4 * n_out + 1, seed=822) % np.uint64(K)).astype(np.int64))).unique()[:n_out]
+    W[:, oidx] *= 30.0
+    W = W.to(dt)
+    W0 = W.clone()
+    W0[:, oidx] = 0
+    q, s = oracle.quantize_rowwise(W0)
+    ow = W[:, oidx].contiguous()
+    b = synthetic.normal((N,), dt, seed=823) if bias else None
+    x = synthetic.normal((M, K), dt, seed=824)
+    y = bnb.outlier_linear(x.to(DEV), q.to(DEV), s.to(DEV), oidx.to(DEV), ow.to(DEV), None if b is None else b.to(DEV), dt)
+    rows = torch.arange(0, M, max(1, M // 64))[:64]           # rows are independent: a row sample bounds the oracle's time
+    ref = oracle.outlier_linear(x[rows], q, s, oidx, ow, b)
+    err = rel_fro(y.cpu()[rows], ref)
+    assert err <= OA_TOL[dt], err

@@ -145,3 +145,28 @@ def test_memory_footprint_counts_quantized_buffers():
     fp = bnb.get_memory_footprint(m)
     assert fp["quantized_params"] == 64 * 32 // 2 + 32 * 16
     assert fp["total_params"] > 0 and fp["actual_size_gb"] > 0
+
+
+def test_embedding_and_outlier_modules_mirror_reference_without_a_gpu():
+    """Constructors, buffers, validation messages and the no-CPU-path rule of the §8f rank-3 modules."""
+    e4 = bnb.Embedding4bit(100, 64, padding_idx=3, quant_type="fp4", blocksize=32)
+    assert sorted(e4.state_dict()) == ["weight_absmax", "weight_packed"]
+    assert e4.weight_packed.shape == (100, 32) and e4.weight_packed.dtype == torch.uint8 and e4.weight_absmax.shape == (100, 2)
+    assert "quant_type=fp4" in e4.extra_repr()
+    with pytest.raises(ValueError, match="embedding_dim must be even"):
+        bnb.Embedding4bit(10, 15)
+    with pytest.raises(ValueError, match="quant_type must be 'nf4' or 'fp4'"):
+        bnb.Embedding4bit(10, 16, quant_type="int4")
+    e8 = bnb.Embedding8bit(100, 70, padding_idx=0)
+    assert sorted(e8.state_dict()) == ["weight_int8", "weight_scales"] and e8.weight_int8.shape == (100, 70)
+    assert bnb.EmbeddingNF4(10, 16).quant_type == "nf4" and bnb.EmbeddingFP4(10, 16).quant_type == "fp4"
+    oa = bnb.OutlierAwareLinear(64, 32, bias=True, threshold=5.0)
+    assert sorted(oa.state_dict()) == ["bias", "outlier_indices", "outlier_weights", "weight_int8", "weight_scales"]
+    assert oa.outlier_weights.shape == (32, 0) and oa.outlier_indices.dtype == torch.long and "outliers=0" in oa.extra_repr()
+    assert bnb.OutlierAwareLinear(8, 4, bias=False).bias is None
+    # no CPU path: CPU tensors are rejected, nothing falls back
+    for fn in (lambda: e4(torch.tensor([1, 2])), lambda: e8(torch.tensor([1, 2])), lambda: oa(torch.zeros(2, 64)),
+               lambda: bnb.Embedding4bit.from_embedding(torch.nn.Embedding(8, 64).half()),
+               lambda: bnb.OutlierAwareLinear.from_linear(torch.nn.Linear(64, 8).half())):
+        with pytest.raises(ValueError, match="requires tensor on a 'cuda'"):
+            fn()
