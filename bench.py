@@ -43,8 +43,9 @@ def parse():
     ap.add_argument("--no-empirical", action="store_true", help="skip the vendor-BLAS / copy-bandwidth context figures")
     ap.add_argument("--warmup", type=int, default=100)  # ~13 ms: the GPU clock needs a few ms of load to ramp
     ap.add_argument("--workload", default="nf4_m4096",
-                    choices=["nf4_m4096", "nf4dq_ffn", "int8_4096", "nf4_m1"],
-                    help="nf4_m4096 = the BASELINE metric (default); the others are BASELINE configs 3, 4 and 2")
+                    choices=["nf4_m4096", "nf4dq_ffn", "int8_4096", "nf4_m1", "embed4", "embed8", "outlier"],
+                    help="nf4_m4096 = the BASELINE metric (default); nf4dq_ffn / int8_4096 / nf4_m1 = BASELINE configs 3, 4, 2; "
+                         "embed4 / embed8 / outlier = the SURVEY 8f rank-3 rows (single GPU)")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the output all-gather (GEMM-only scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemv", action="store_true")
@@ -62,6 +63,101 @@ def event_time_ms(fn, steps):
     e1.record(st)
     e1.synchronize()
     return e0.elapsed_time(e1) / steps
+
+
+def bench_nn(args, wl, dev, bnb, synthetic):
+    """SURVEY 8f rank-3 rows on one GPU: 4-bit / 8-bit embedding lookups (HBM-bound gathers over a 32000 x 4096 table,
+    8192 looked-up rows per step) and OutlierAwareLinear.forward (4096^3, 16 outlier columns, int8 MFMA)."""
+    import numpy as np
+    import oracle
+    out = {"n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "data": "synthetic"}
+    if wl in ("embed4", "embed8"):
+        num, dim, tokens, dt = 32000, 4096, 8192, torch.bfloat16
+        W = synthetic.normal((num, dim), dt, seed=1234, std=0.5).to(dev)
+        idx_cpu = torch.from_numpy((synthetic.uniform_u64(tokens, seed=4321) % np.uint64(num)).astype(np.int64))
+        idx = idx_cpu.to(dev)
+        if wl == "embed4":
+            packed, st = bnb.quantize_nf4(W, blocksize=64)
+            packed, absmax = packed.view(num, dim // 2), st.absmax.view(num, -1)
+            step = lambda: bnb.embedding_4bit(idx, packed, absmax, dim, 64, "nf4", None, dt)
+            bytes_per_row = dim // 2 + (dim // 64) * 4 + dim * 2 + 8
+            cpu = lambda: oracle.embedding_4bit(idx_cpu, packed.cpu(), absmax.cpu(), dim, 64, "nf4", None, dt)
+            label = "Embedding4bit (NF4 bs64)"
+        else:
+            q, sc = bnb.quantize_rowwise(W)
+            step = lambda: bnb.embedding_8bit(idx, q, sc, None, dt)
+            bytes_per_row = dim + 4 + dim * 2 + 8
+            qc, scc = q.cpu(), sc.cpu()
+            cpu = lambda: oracle.embedding_8bit(idx_cpu, qc, scc, None, dt)
+            label = "Embedding8bit"
+        del W
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        kern_ms = event_time_ms(step, args.steps)
+        nbytes = bytes_per_row * tokens
+        gbs = nbytes / (kern_ms * 1e-3) / 1e9
+        out.update({"metric": f"effective GB/s, {label} lookup of {tokens} rows from a {num} x {dim} table -> bf16",
+                    "value": round(nbytes / (elapsed / args.steps) / 1e9, 1), "unit": "GB/s",
+                    "ms_per_step": round(elapsed / args.steps * 1e3, 5), "dtype": "u8" if wl == "embed4" else "int8",
+                    "config": {"workload": f"{label}.forward, vocabulary {num}, embedding_dim {dim}, {tokens} indices per step",
+                               "algorithmic_bytes_per_row": bytes_per_row},
+                    "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                 "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None, "kernel_us": round(kern_ms * 1e3, 2)}})
+        if not args.no_cpu_baseline:
+            cpu()
+            t0, n = time.perf_counter(), 0
+            while time.perf_counter() - t0 < min(args.cpu_seconds, 5.0):
+                cpu()
+                n += 1
+            dtc = (time.perf_counter() - t0) / n
+            out["cpu_baseline"] = {"value": round(nbytes / dtc / 1e9, 2), "unit": "GB/s", "cores": oracle.num_threads(),
+                                   "kind": "port", "sample": f"{n} x the full step on the host (oracle, OpenMP)"}
+        return out
+    M = N = K = 4096
+    dt, n_out = torch.float16, 16
+    W = synthetic.normal((N, K), torch.float32, seed=1234, std=0.05)
+    oidx = torch.arange(100, 100 + 250 * n_out, 250)
+    W[:, oidx] *= 30.0
+    lin = torch.nn.Linear(K, N, bias=True)
+    lin.weight.data.copy_(W)
+    oa = bnb.OutlierAwareLinear.from_linear(lin.to(dt).to(dev))
+    assert int(oa.outlier_indices.numel()) == n_out
+    x = synthetic.normal((M, K), dt, seed=4321).to(dev)
+    step = lambda: oa(x)
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kern_ms = event_time_ms(step, args.steps)
+    ops = 2.0 * M * N * K
+    tops = ops / (kern_ms * 1e-3) / 1e12
+    out.update({"metric": "effective TOP/s, OutlierAwareLinear.forward 4096x4096 @ M=4096 (row-wise int8 quantise + int8 MFMA + 16 outlier columns + bias)",
+                "value": round(ops / (elapsed / args.steps) / 1e12, 1), "unit": "TOP/s", "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+                "dtype": "int8", "config": {"workload": "OutlierAwareLinear.forward, fp16 activations, 16 outlier columns, bias", "M": M, "N": N, "K": K},
+                "roofline": {"bound": "mfma", "achieved": round(tops, 1), "peak": PEAK_TFLOPS["int8"], "unit": "TOP/s",
+                             "frac": round(tops / PEAK_TFLOPS["int8"], 4), "traffic": None, "kernel_us": round(kern_ms * 1e3, 2),
+                             "note": "whole forward (3 kernels) / int8 dense peak"}})
+    if not args.no_cpu_baseline:
+        rows = 256
+        xs = x[:rows].cpu()
+        q, sc, oi, ow, b = oa.weight_int8.cpu(), oa.weight_scales.cpu(), oa.outlier_indices.cpu(), oa.outlier_weights.cpu(), oa.bias.cpu()
+        t0 = time.perf_counter()
+        oracle.outlier_linear(xs, q, sc, oi, ow, b)
+        dtc = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(2.0 * rows * N * K / dtc / 1e12, 4), "unit": "TOP/s", "cores": oracle.num_threads(),
+                               "kind": "port", "sample": f"{rows} of the {M} rows, one pass (oracle, OpenMP)"}
+    return out
 
 
 def cpu_baseline(args, M, N, K, blocksize, compress, dtype):
@@ -116,6 +212,10 @@ def main():
     _native.lib()  # fail loudly when the HIP library is missing
 
     wl = args.workload
+    if wl in ("embed4", "embed8", "outlier"):
+        if rank == 0:
+            print(json.dumps(bench_nn(args, wl, dev, bnb, synthetic)))
+        return
     if wl == "nf4_m4096":
         M, N, K, dt, compress, name = 4096, 4096, 4096, torch.bfloat16, False, "bf16"
     elif wl == "nf4dq_ffn":

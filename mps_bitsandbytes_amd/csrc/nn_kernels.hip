@@ -39,14 +39,16 @@ __global__ __launch_bounds__(256) void k_embedding_4bit(const int64_t *__restric
     const uint8_t *prow = packed + rr * (dim >> 1);
     const float *arow = absmax + rr * nblk;
     OutT *orow = out + t * dim;
-    const int64_t nvec = vec_ok ? dim / 8 : 0;
-    for (int64_t g = threadIdx.x; g < nvec; g += blockDim.x) {
+    const int nvec = vec_ok ? (int)(dim / 8) : 0;
+    const bool one_am = (blocksize % 8) == 0;   // the 8 values of a group share one absmax block
+    for (int g = threadIdx.x; g < nvec; g += blockDim.x) {
         const uint32_t w = *reinterpret_cast<const uint32_t *>(prow + g * 4);
         __attribute__((aligned(16))) OutT o[8];
+        const float am = one_am ? arow[(g * 8) / blocksize] : 0.0f;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const int64_t k = g * 8 + 2 * j;
-            const float a0 = arow[k / blocksize], a1 = arow[(k + 1) / blocksize];
+            const int k = g * 8 + 2 * j;
+            const float a0 = one_am ? am : arow[k / blocksize], a1 = one_am ? am : arow[(k + 1) / blocksize];
             const uint32_t b = (w >> (8 * j)) & 0xFFu;
             o[2 * j] = from_f32<OutT>(zero ? 0.0f : lut[b & 15] * a0);
             o[2 * j + 1] = from_f32<OutT>(zero ? 0.0f : lut[b >> 4] * a1);
@@ -58,7 +60,7 @@ __global__ __launch_bounds__(256) void k_embedding_4bit(const int64_t *__restric
             for (int j = 0; j < 8; j++) orow[g * 8 + j] = o[j];
         }
     }
-    for (int64_t k = nvec * 8 + threadIdx.x; k < dim; k += blockDim.x) {
+    for (int64_t k = (int64_t)nvec * 8 + threadIdx.x; k < dim; k += blockDim.x) {
         const uint8_t b = prow[k >> 1];
         const int nib = (k & 1) ? (b >> 4) : (b & 15);
         orow[k] = from_f32<OutT>(zero ? 0.0f : lut[nib] * arow[k / blocksize]);
@@ -145,23 +147,51 @@ int embedding_8bit_dispatch(const int64_t *idx, int64_t n_idx, const int8_t *W, 
 }
 
 // ------------------------------------------------------------------------------------ outlier-aware linear
-__global__ void k_set_mask(const int64_t *__restrict__ idx, int64_t n, int64_t K, uint8_t *__restrict__ mask) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && idx[i] >= 0 && idx[i] < K) mask[idx[i]] = 1;
-}
-
 // quantize_rowwise (functional.py:607-625) of x[:, non-outlier columns] (nn/outlier_aware.py:121-131), written at
 // full width with zeros in the outlier columns: a zero neither raises the row absmax nor contributes to the
 // integer dot product, so the contraction can run over the whole K with the stored int8 weight.
 template <typename T>
 __global__ __launch_bounds__(256) void k_quantize_rowwise_masked(const T *__restrict__ A, int64_t rows, int64_t cols,
-                                                                const uint8_t *__restrict__ mask, int8_t *__restrict__ out,
-                                                                float *__restrict__ scales) {
+                                                                const int64_t *__restrict__ oidx, int64_t n_out,
+                                                                int8_t *__restrict__ out, float *__restrict__ scales,
+                                                                bool vec_ok) {
+    // column mask of the outlier set, rebuilt per workgroup in LDS (cols bytes, rounded up to 8): cheaper than a
+    // global mask + two extra launches for the handful of outlier columns of a layer
+    extern __shared__ __attribute__((aligned(8))) uint8_t mask[];
     __shared__ float red[4];
+    for (int64_t c = (int64_t)threadIdx.x * 8; c < cols; c += 256 * 8) *reinterpret_cast<u32x2 *>(mask + c) = u32x2{0u, 0u};
+    __syncthreads();
+    for (int64_t j = threadIdx.x; j < n_out; j += 256)
+        if (oidx[j] >= 0 && oidx[j] < cols) mask[oidx[j]] = 1;
+    __syncthreads();
     const int64_t r = blockIdx.x;
     const T *row = A + r * cols;
+    auto load8m = [&](int64_t k0, float (&x)[8]) {   // 8 values with the outlier columns zeroed
+        const u32x2 mk = *reinterpret_cast<const u32x2 *>(mask + k0);
+        if constexpr (sizeof(T) == 2) {
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(row + k0);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                x[2 * j] = unpack_lo<T>(v[j]);
+                x[2 * j + 1] = unpack_hi<T>(v[j]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) x[j] = to_f32(row[k0 + j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if ((mk[j >> 2] >> (8 * (j & 3))) & 0xFFu) x[j] = 0.0f;
+    };
     float am = 0.0f;
-    for (int64_t c = threadIdx.x; c < cols; c += 256) am = fmaxf(am, mask[c] ? 0.0f : fabsf(to_f32(row[c])));
+    const int64_t nvec = vec_ok ? cols / 8 : 0;
+    for (int64_t g = threadIdx.x; g < nvec; g += 256) {
+        float x[8];
+        load8m(g * 8, x);
+#pragma unroll
+        for (int j = 0; j < 8; j++) am = fmaxf(am, fabsf(x[j]));
+    }
+    for (int64_t c = nvec * 8 + threadIdx.x; c < cols; c += 256) am = fmaxf(am, mask[c] ? 0.0f : fabsf(to_f32(row[c])));
     am = wave_max(am);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = am;
     __syncthreads();
@@ -169,56 +199,149 @@ __global__ __launch_bounds__(256) void k_quantize_rowwise_masked(const T *__rest
     if (threadIdx.x == 0) scales[r] = am;
     const float s = rscale127(am);
     int8_t *orow = out + r * cols;
-    for (int64_t c = threadIdx.x; c < cols; c += 256) orow[c] = mask[c] ? (int8_t)0 : quant_i8(to_f32(row[c]), s);
+    for (int64_t g = threadIdx.x; g < nvec; g += 256) {
+        float x[8];
+        load8m(g * 8, x);
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            lo |= (uint32_t)(uint8_t)quant_i8(x[j], s) << (8 * j);
+            hi |= (uint32_t)(uint8_t)quant_i8(x[4 + j], s) << (8 * j);
+        }
+        *reinterpret_cast<u32x2 *>(orow + g * 8) = u32x2{lo, hi};
+    }
+    for (int64_t c = nvec * 8 + threadIdx.x; c < cols; c += 256) orow[c] = mask[c] ? (int8_t)0 : quant_i8(to_f32(row[c]), s);
 }
 
 // out[m, n] <- RNE(RNE(out[m, n] + RNE(sum_j x[m, idx_j] * ow[n, j])) + bias[n])   (nn/outlier_aware.py:141-143, :110-111);
-// without outliers only the bias add.  One thread per output element; the x values of a row are shared by the
-// whole workgroup (one m per block row), ow[n, :] is contiguous.
+// without outliers only the bias add.  A workgroup owns 16 rows x 512 columns, a thread 16 rows x 2 consecutive
+// columns (4-byte accesses to `out` for 16-bit types; its outlier weights come as 16-byte loads when n_out % 8 == 0).  The rows' outlier activations are gathered once into LDS
+// (chunks of 16 outliers, broadcast ds_read_b128), the thread's outlier weights of the chunk live in registers;
+// f32 accumulation.
 template <typename T>
 __global__ __launch_bounds__(256) void k_outlier_add(const T *__restrict__ X, int64_t M, int64_t K, int64_t N,
                                                     const int64_t *__restrict__ oidx, int64_t n_out,
                                                     const T *__restrict__ ow, const T *__restrict__ bias,
-                                                    T *__restrict__ out) {
-    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t m = blockIdx.y;
-    if (n >= N) return;
-    float v = to_f32(out[m * N + n]);
-    if (n_out > 0) {
-        float o = 0.0f;
-        for (int64_t j = 0; j < n_out; j++) o = fmaf(to_f32(X[m * K + oidx[j]]), to_f32(ow[n * n_out + j]), o);
-        v = to_f32(from_f32<T>(v + to_f32(from_f32<T>(o))));
+                                                    T *__restrict__ out, bool vec_ok, bool ow_vec) {
+    constexpr int RM = 16, CN = 2, CH = 16;
+    __shared__ __attribute__((aligned(16))) float xs[RM][CH];
+    const int64_t n0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * CN;
+    const int64_t m0 = (int64_t)blockIdx.y * RM;
+    float acc[RM][CN];
+#pragma unroll
+    for (int i = 0; i < RM; i++)
+#pragma unroll
+        for (int c = 0; c < CN; c++) acc[i][c] = 0.0f;
+    for (int64_t j0 = 0; j0 < n_out; j0 += CH) {
+        __syncthreads();
+        {
+            const int i = threadIdx.x / CH, j = threadIdx.x % CH;   // 256 threads = RM x CH values
+            const int64_t m = m0 + i;
+            xs[i][j] = (m < M && j0 + j < n_out) ? to_f32(X[m * K + oidx[j0 + j]]) : 0.0f;
+        }
+        __syncthreads();
+        float w[CN][CH];
+        if constexpr (sizeof(T) == 2) {
+            if (ow_vec && n0 + CN <= N && j0 + CH <= n_out) {   // 2 x 16-byte loads per column
+#pragma unroll
+                for (int c = 0; c < CN; c++)
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        const u32x4 v = *reinterpret_cast<const u32x4 *>(ow + (n0 + c) * n_out + j0 + 8 * h);
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            w[c][8 * h + 2 * e] = unpack_lo<T>(v[e]);
+                            w[c][8 * h + 2 * e + 1] = unpack_hi<T>(v[e]);
+                        }
+                    }
+            } else {
+#pragma unroll
+                for (int c = 0; c < CN; c++)
+#pragma unroll
+                    for (int j = 0; j < CH; j++)
+                        w[c][j] = (n0 + c < N && j0 + j < n_out) ? to_f32(ow[(n0 + c) * n_out + j0 + j]) : 0.0f;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < CN; c++)
+#pragma unroll
+                for (int j = 0; j < CH; j++)
+                    w[c][j] = (n0 + c < N && j0 + j < n_out) ? to_f32(ow[(n0 + c) * n_out + j0 + j]) : 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < RM; i++)
+#pragma unroll
+            for (int q = 0; q < CH / 4; q++) {
+                const f32x4 xv = *reinterpret_cast<const f32x4 *>(&xs[i][4 * q]);   // one broadcast ds_read_b128
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+#pragma unroll
+                    for (int c = 0; c < CN; c++) acc[i][c] = fmaf(xv[e], w[c][4 * q + e], acc[i][c]);
+            }
     }
-    if (bias) v = to_f32(from_f32<T>(v + to_f32(bias[n])));
-    out[m * N + n] = from_f32<T>(v);
+    if (n0 >= N) return;
+    float b[CN];
+#pragma unroll
+    for (int c = 0; c < CN; c++) b[c] = (bias && n0 + c < N) ? to_f32(bias[n0 + c]) : 0.0f;
+    const bool full = vec_ok && n0 + CN <= N;
+#pragma unroll
+    for (int i = 0; i < RM; i++) {
+        const int64_t m = m0 + i;
+        if (m >= M) break;
+        T *p = out + m * N + n0;
+        __attribute__((aligned(8))) T v[CN];
+        if (full) {
+            if constexpr (sizeof(T) == 2) *reinterpret_cast<uint32_t *>(v) = *reinterpret_cast<const uint32_t *>(p);
+            else *reinterpret_cast<u32x2 *>(v) = *reinterpret_cast<const u32x2 *>(p);
+        } else {
+#pragma unroll
+            for (int c = 0; c < CN; c++) v[c] = (n0 + c < N) ? p[c] : from_f32<T>(0.0f);
+        }
+#pragma unroll
+        for (int c = 0; c < CN; c++) {
+            float f = to_f32(v[c]);
+            if (n_out > 0) f = to_f32(from_f32<T>(f + to_f32(from_f32<T>(acc[i][c]))));
+            if (bias) f = to_f32(from_f32<T>(f + b[c]));
+            v[c] = from_f32<T>(f);
+        }
+        if (full) {
+            if constexpr (sizeof(T) == 2) *reinterpret_cast<uint32_t *>(p) = *reinterpret_cast<const uint32_t *>(v);
+            else *reinterpret_cast<u32x2 *>(p) = *reinterpret_cast<const u32x2 *>(v);
+        } else {
+#pragma unroll
+            for (int c = 0; c < CN; c++)
+                if (n0 + c < N) p[c] = v[c];
+        }
+    }
 }
 
 template <typename T>
 static int launch_outlier_linear(const void *X, int64_t M, int64_t K, const int8_t *W, const float *w_scales, int64_t N,
                                  const int64_t *oidx, int64_t n_out, const void *ow, const void *bias, void *out,
                                  void *workspace, int dtype, hipStream_t st) {
-    // workspace: [x_q int8 M*K | pad to 256][x_scales f32 M | pad to 256][mask u8 K]
+    // workspace: [x_q int8 M*K | pad to 256][x_scales f32 M]
     char *ws = static_cast<char *>(workspace);
     int8_t *xq = reinterpret_cast<int8_t *>(ws);
     const int64_t off_s = (M * K + 255) & ~(int64_t)255;
     float *xs = reinterpret_cast<float *>(ws + off_s);
-    const int64_t off_m = off_s + ((4 * M + 255) & ~(int64_t)255);
-    uint8_t *mask = reinterpret_cast<uint8_t *>(ws + off_m);
-    hipError_t e = hipMemsetAsync(mask, 0, (size_t)K, st);
-    if (e != hipSuccess) {
-        set_error("outlier_linear: hipMemsetAsync failed: %s", hipGetErrorString(e));
-        return (int)e;
+    const size_t mask_lds = (size_t)((K + 7) & ~(int64_t)7);
+    if (mask_lds > 65536) {
+        set_error("outlier_linear: in_features %lld too large for the LDS column mask", (long long)K);
+        return MBNB_ERR_ARG;
     }
-    if (n_out > 0) hipLaunchKernelGGL(k_set_mask, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, st, oidx, n_out, K, mask);
-    hipLaunchKernelGGL(k_quantize_rowwise_masked<T>, dim3((unsigned)M), dim3(256), 0, st, static_cast<const T *>(X), M, K, mask, xq, xs);
+    const bool vec_ok = (K % 8 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+    hipLaunchKernelGGL(k_quantize_rowwise_masked<T>, dim3((unsigned)M), dim3(256), mask_lds, st, static_cast<const T *>(X), M, K,
+                       oidx, n_out, xq, xs, vec_ok);
     int rc = check_launch("outlier_linear(quantize)");
     if (rc) return rc;
     rc = matmul_int8_nt_dispatch(xq, W, xs, w_scales, M, N, K, dtype, out, st);
     if (rc) return rc;
     if (n_out > 0 || bias) {
-        dim3 grid((unsigned)((N + 255) / 256), (unsigned)M);
+        dim3 grid((unsigned)((N + 511) / 512), (unsigned)((M + 15) / 16));
+        const bool vec_out = (N % 2 == 0) && ((reinterpret_cast<uintptr_t>(out) & 7) == 0);
+        const bool ow_vec = (n_out % 8 == 0) && ((reinterpret_cast<uintptr_t>(ow) & 15) == 0);
         hipLaunchKernelGGL(k_outlier_add<T>, grid, dim3(256), 0, st, static_cast<const T *>(X), M, K, N, oidx, n_out,
-                           static_cast<const T *>(ow), static_cast<const T *>(bias), static_cast<T *>(out));
+                           static_cast<const T *>(ow), static_cast<const T *>(bias), static_cast<T *>(out), vec_out, ow_vec);
         rc = check_launch("outlier_linear(outlier add)");
     }
     return rc;
