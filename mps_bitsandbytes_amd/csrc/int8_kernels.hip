@@ -25,6 +25,30 @@ __global__ __launch_bounds__(256) void k_transpose_i8(const int8_t *__restrict__
     }
 }
 
+// 64 x 64 tiles with 4 x 4 byte blocks transposed in registers (v_perm_b32): a thread loads 4 bytes (4 n) of 4
+// consecutive k rows -- a wave's load covers 64-byte row segments --, writes the 4 transposed dwords into an LDS
+// tile [n][k] and stores 16 bytes (16 k of one n): 4 lanes complete a 64-byte segment of a Bt row.
+// Needs K % 64 == 0, N % 64 == 0 and 16-byte aligned pointers.
+__global__ __launch_bounds__(256) void k_transpose_i8_64(const int8_t *__restrict__ B, int8_t *__restrict__ Bt, int64_t K,
+                                                        int64_t N) {
+    __shared__ __attribute__((aligned(16))) uint32_t tile[64][17];   // [n][k / 4], one dword of padding per row
+    const int64_t k0 = (int64_t)blockIdx.y * 64, n0 = (int64_t)blockIdx.x * 64;
+    const int n4 = threadIdx.x & 15, kg = threadIdx.x >> 4;
+    uint32_t r[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) r[j] = *reinterpret_cast<const uint32_t *>(B + (k0 + 4 * kg + j) * N + n0 + 4 * n4);
+    const uint32_t t0 = __builtin_amdgcn_perm(r[1], r[0], 0x05010400u), t1 = __builtin_amdgcn_perm(r[1], r[0], 0x07030602u);
+    const uint32_t t2 = __builtin_amdgcn_perm(r[3], r[2], 0x05010400u), t3 = __builtin_amdgcn_perm(r[3], r[2], 0x07030602u);
+    tile[4 * n4 + 0][kg] = __builtin_amdgcn_perm(t2, t0, 0x05040100u);
+    tile[4 * n4 + 1][kg] = __builtin_amdgcn_perm(t2, t0, 0x07060302u);
+    tile[4 * n4 + 2][kg] = __builtin_amdgcn_perm(t3, t1, 0x05040100u);
+    tile[4 * n4 + 3][kg] = __builtin_amdgcn_perm(t3, t1, 0x07060302u);
+    __syncthreads();
+    const int n = threadIdx.x >> 2, kc = threadIdx.x & 3;
+    const u32x4 v = u32x4{tile[n][4 * kc], tile[n][4 * kc + 1], tile[n][4 * kc + 2], tile[n][4 * kc + 3]};
+    *reinterpret_cast<u32x4 *>(Bt + (n0 + n) * K + k0 + 16 * kc) = v;
+}
+
 // ------------------------------------------------------------------ int8 x int8 MFMA GEMM
 // Tile 128 x 128 x 128(k, int8) -> the same 128-byte-row swizzled LDS images as gemm_tile.h.
 // Orientation as there: Bt rows (n) are the MFMA "A" operand, A rows (m) the "B" operand.
@@ -377,7 +401,10 @@ int matmul_int8_dispatch(const int8_t *A, const int8_t *B, const float *sA, cons
         return check_launch("matmul_int8(generic)");
     }
     int8_t *Bt = static_cast<int8_t *>(workspace);
-    hipLaunchKernelGGL(k_transpose_i8, dim3((unsigned)((N + 63) / 64), (unsigned)((K + 63) / 64)), dim3(256), 0, st, B, Bt, K, N);
+    if ((K % 64 == 0) && (N % 64 == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0))
+        hipLaunchKernelGGL(k_transpose_i8_64, dim3((unsigned)(N / 64), (unsigned)(K / 64)), dim3(256), 0, st, B, Bt, K, N);
+    else
+        hipLaunchKernelGGL(k_transpose_i8, dim3((unsigned)((N + 63) / 64), (unsigned)((K + 63) / 64)), dim3(256), 0, st, B, Bt, K, N);
     return matmul_int8_nt_dispatch(A, Bt, sA, sB, M, N, K, out_dtype, out, st);
 }
 
