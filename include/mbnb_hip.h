@@ -128,6 +128,17 @@ int mbnb_matmul_4bit(const void *A, int64_t M, int64_t K, const uint8_t *packed,
                      int quant_type, int w_dtype, const void *bias, int out_dtype, void *out,
                      void *stream);
 
+/* matmul_4bit with a caller-provided split-K workspace.  Between the GEMV shapes (M <= 4) and the shapes that fill the
+ * chip with 256 x 256 tiles, the output has too few tiles for 256 CUs; with a workspace of
+ * mbnb_matmul_4bit_workspace_bytes(M, N, K) bytes (0 = not needed; 16-byte aligned) the contraction is split into K
+ * slices whose f32 partial sums are added in slice order (deterministic) before the bias and the rounding.
+ * Same results contract as mbnb_matmul_4bit; workspace == NULL behaves exactly like it. */
+int64_t mbnb_matmul_4bit_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int mbnb_matmul_4bit_ws(const void *A, int64_t M, int64_t K, const uint8_t *packed,
+                        const mbnb_absmax *absmax, int64_t N, int64_t K_weight, int blocksize,
+                        int quant_type, int w_dtype, const void *bias, int out_dtype, void *out,
+                        void *workspace, int64_t workspace_bytes, void *stream);
+
 /* ---------------------------------------------------------------------------
  * matmul_int8 — replaces `_C.matmul_int8` (mm:1789-1834, kernel mm:155-196) /
  * functional.matmul_int8 (functional.py:788-793):

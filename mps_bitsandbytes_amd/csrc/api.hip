@@ -37,6 +37,8 @@ int quantize_rowwise_dispatch(const void *, int, int64_t, int64_t, int8_t *, flo
 int dequantize_rowwise_dispatch(const int8_t *, const float *, int64_t, int64_t, int, void *, hipStream_t);
 int double_quant_dispatch(const void *, int, int64_t, int64_t, int8_t *, int8_t *, float *, float *, int, int, hipStream_t);
 int matmul_4bit_dispatch(const void *, int64_t, int64_t, const uint8_t *, const AbsmaxView &, int64_t, int64_t, int, int, int, const void *, int, void *, hipStream_t);
+void set_matmul4_workspace(void *, int64_t);
+int64_t matmul4_splitk_slices(int64_t, int64_t, int64_t);
 int matmul_int8_dispatch(const int8_t *, const int8_t *, const float *, const float *, int64_t, int64_t, int64_t, int, void *, void *, hipStream_t);
 int linear_int8_dispatch(const void *, int, int64_t, int64_t, const int8_t *, const float *, int64_t, const void *, void *, hipStream_t);
 int embedding_4bit_dispatch(const int64_t *, int64_t, const uint8_t *, const float *, int64_t, int64_t, int, int, int, int64_t, int, void *, hipStream_t);
@@ -173,6 +175,22 @@ int mbnb_matmul_4bit(const void *A, int64_t M, int64_t K, const uint8_t *packed,
     if (!A || !packed || !out) return fail(MBNB_ERR_ARG, "matmul_4bit: NULL pointer");
     return matmul_4bit_dispatch(A, M, K, packed, v, N, K_weight, blocksize, quant_type, w_dtype, bias, out_dtype, out,
                                 static_cast<hipStream_t>(stream));
+}
+
+int64_t mbnb_matmul_4bit_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const int64_t s = matmul4_splitk_slices(M, N, K);
+    return s > 1 ? s * ((M + 127) / 128) * ((N + 127) / 128) * 65536 : 0;   // slices x tiles x 128 x 128 f32
+}
+
+int mbnb_matmul_4bit_ws(const void *A, int64_t M, int64_t K, const uint8_t *packed, const mbnb_absmax *absmax, int64_t N,
+                        int64_t K_weight, int blocksize, int quant_type, int w_dtype, const void *bias, int out_dtype,
+                        void *out, void *workspace, int64_t workspace_bytes, void *stream) {
+    set_matmul4_workspace(workspace, workspace ? workspace_bytes : 0);
+    const int rc = mbnb_matmul_4bit(A, M, K, packed, absmax, N, K_weight, blocksize, quant_type, w_dtype, bias, out_dtype, out,
+                                    stream);
+    set_matmul4_workspace(nullptr, 0);
+    return rc;
 }
 
 int mbnb_matmul_int8(const int8_t *A, const int8_t *B, const float *A_scales, const float *B_scales, int64_t M,

@@ -144,7 +144,8 @@ template <typename T> struct I8Producer {
 template <typename T, typename OutT, typename Producer, int BM, int BN>
 __global__ __launch_bounds__(256, 2) void k_gemm_decode(const T *__restrict__ X, typename Producer::Params wp,
                                                         const T *__restrict__ bias, OutT *__restrict__ out, int64_t M,
-                                                        int64_t N, int64_t K) {
+                                                        int64_t N, int64_t K, float *__restrict__ partial = nullptr,
+                                                        int64_t k_per_slice = 0) {
     static_assert(BM % 64 == 0 && BN % 64 == 0, "tile");
     constexpr int A_BYTES = BM * ROW_BYTES;
     constexpr int B_BYTES = BN * ROW_BYTES;
@@ -211,14 +212,18 @@ __global__ __launch_bounds__(256, 2) void k_gemm_decode(const T *__restrict__ X,
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
 
-    const int64_t nk = (K + BK - 1) / BK;
-    fetch_tile(0);
+    // split-K (partial != nullptr): workgroup (x, y) contracts k in [y * k_per_slice, (y + 1) * k_per_slice) and
+    // writes raw f32 partial sums to partial[y][M][N]; k_splitk_reduce adds the slices in order, then bias + rounding
+    const int64_t k_begin = partial ? (int64_t)blockIdx.y * k_per_slice : 0;
+    const int64_t k_end = partial ? (k_begin + k_per_slice < K ? k_begin + k_per_slice : K) : K;
+    const int64_t nk = (k_end - k_begin + BK - 1) / BK;
+    fetch_tile(k_begin);
     stage_tile(0);
     const int fr = lane & 31, fh = lane >> 5;
     for (int64_t kt = 0; kt < nk; kt++) {
         const int buf = (int)(kt & 1);
         __syncthreads();  // tile kt visible; buffer buf^1 free (its readers finished before this barrier)
-        if (kt + 1 < nk) fetch_tile((kt + 1) * BK);
+        if (kt + 1 < nk) fetch_tile(k_begin + (kt + 1) * BK);
         const char *As = smem + buf * STAGE;
         const char *Bs = As + A_BYTES;
 #pragma unroll
@@ -248,6 +253,12 @@ __global__ __launch_bounds__(256, 2) void k_gemm_decode(const T *__restrict__ X,
             for (int g = 0; g < 4; g++) {
                 const int64_t n = n0 + wn * (BN / 2) + i * 32 + 8 * g + 4 * fh;
                 if (m >= M || n >= N) continue;
+                if (partial) {
+                    // accumulator order: [slice][tile][wave][i*TM+j][g][lane][4] -- a wave's store is 1 KiB contiguous
+                    float *pp = partial + (((((int64_t)blockIdx.y * nwg + bid) * 4 + wave) * (TN * TM) + (i * TM + j)) * 4 + g) * 256 + lane * 4;
+                    *reinterpret_cast<f32x4 *>(pp) = f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                    continue;
+                }
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
@@ -269,6 +280,46 @@ __global__ __launch_bounds__(256, 2) void k_gemm_decode(const T *__restrict__ X,
                 }
             }
         }
+}
+
+// out[m, n] = cast_out(round_T(sum_s partial[s][...] + bias[n])): slices added in index order (deterministic).
+// partial is in the 128 x 128 kernel's accumulator order [slice][tile][wave][i*2+j][g][lane][4] (TN = TM = 2), so
+// both the GEMM's stores and these loads are 1 KiB-contiguous per wave; a thread owns 4 consecutive n of one m.
+template <typename T, typename OutT>
+__global__ __launch_bounds__(256) void k_splitk_reduce(const float *__restrict__ partial, int slices, const T *__restrict__ bias,
+                                                      OutT *__restrict__ out, int64_t M, int64_t N, int64_t tiles_m,
+                                                      int64_t nwg) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;   // = ((((tile*4 + wave)*4 + ij)*4 + g)*64 + lane)
+    if (t >= nwg * 4096) return;
+    const int lane = (int)(t & 63), g = (int)((t >> 6) & 3), ij = (int)((t >> 8) & 3), wave = (int)((t >> 10) & 3);
+    const int64_t tile = t >> 12;
+    const int i = ij >> 1, j = ij & 1, wn = wave >> 1, wm = wave & 1;
+    const int64_t m = (tile % tiles_m) * 128 + wm * 64 + j * 32 + (lane & 31);
+    const int64_t n = (tile / tiles_m) * 128 + wn * 64 + i * 32 + 8 * g + 4 * (lane >> 5);
+    if (m >= M || n >= N) return;
+    f32x4 a = *reinterpret_cast<const f32x4 *>(partial + t * 4);
+    const int64_t stride = nwg * 16384;
+    for (int sl = 1; sl < slices; sl++) {
+        const f32x4 b = *reinterpret_cast<const f32x4 *>(partial + (int64_t)sl * stride + t * 4);
+#pragma unroll
+        for (int e = 0; e < 4; e++) a[e] += b[e];
+    }
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        float s = a[e];
+        if (bias != nullptr && n + e < N) s += to_f32(bias[n + e]);
+        v[e] = to_f32(from_f32<T>(s));
+    }
+    OutT *o = out + m * N + n;
+    if (n + 4 <= N && ((reinterpret_cast<uintptr_t>(o) & (4 * sizeof(OutT) - 1)) == 0)) {
+        if constexpr (sizeof(OutT) == 2) *reinterpret_cast<u32x2 *>(o) = u32x2{pack2<OutT>(v[0], v[1]), pack2<OutT>(v[2], v[3])};
+        else *reinterpret_cast<f32x4 *>(o) = f32x4{v[0], v[1], v[2], v[3]};
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+            if (n + e < N) o[e] = from_f32<OutT>(v[e]);
+    }
 }
 
 template <int BM, int BN> constexpr int gemm_decode_lds_bytes() { return 2 * (BM + BN) * ROW_BYTES + 64; }

@@ -466,7 +466,7 @@ static int launch_linear_int8(const void *X, int64_t M, int64_t K, const int8_t 
                 return (int)e;
             }
             const int64_t tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-            hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, st, x, wp, b, o, M, N, K);
+            hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, st, x, wp, b, o, M, N, K, static_cast<float *>(nullptr), (int64_t)0);
             set_kernel_name("w8a16_mfma128");
             return check_launch("linear_int8(mfma)");
         }

@@ -183,7 +183,12 @@ __global__ __launch_bounds__(256) void k_gemv4(const T *__restrict__ X, const ui
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     for (int64_t kbase = 0; kbase < K; kbase += 2048 * KU) {
-        u32x4 xv[KU][MT][4];
+        // activations: from LDS they are fetched quarter by quarter beside the table lookups (xq, two quarters in
+        // flight) so that MT rows x KU chunks never sit in registers at once; without LDS staging (K too large)
+        // all of a trip's activations are requested up front (xv)
+        u32x4 xv[XLDS ? 1 : KU][XLDS ? 1 : MT][4];
+        u32x4 xq[2][MT];
+        int64_t kcs[KU];
 #pragma unroll
         for (int u = 0; u < KU; u++) {
             vf[u] = vf_n[u];
@@ -198,13 +203,13 @@ __global__ __launch_bounds__(256) void k_gemv4(const T *__restrict__ X, const ui
         for (int u = 0; u < KU; u++) {
             const int64_t k0 = kbase + u * 2048 + lane * 32;
             const int64_t kc = k0 < K ? k0 : 0;
+            kcs[u] = kc;
+            if constexpr (!XLDS) {
 #pragma unroll
-            for (int c = 0; c < 4; c++)
+                for (int c = 0; c < 4; c++)
 #pragma unroll
-                for (int i = 0; i < MT; i++) {
-                    if constexpr (XLDS) xv[u][i][c] = *reinterpret_cast<const u32x4 *>(xs + (i * Kp + kc + 8 * c) * 2);
-                    else xv[u][i][c] = *reinterpret_cast<const u32x4 *>(xrow[i] + kc + 8 * c);
-                }
+                    for (int i = 0; i < MT; i++) xv[u][i][c] = *reinterpret_cast<const u32x4 *>(xrow[i] + kc + 8 * c);
+            }
         }
         // keep every load above issued before anything waits on one of them
         __builtin_amdgcn_sched_barrier(0);
@@ -220,6 +225,11 @@ __global__ __launch_bounds__(256) void k_gemv4(const T *__restrict__ X, const ui
             constexpr int q = decltype(qq)::value;
             constexpr int u = q / (NR * 4), r = (q / 4) % NR, c = q % 4;
             const uint32_t w = wq[u][r][c];
+            if constexpr (XLDS) {
+#pragma unroll
+                for (int i = 0; i < MT; i++)
+                    xq[q & 1][i] = *reinterpret_cast<const u32x4 *>(xs + (i * Kp + kcs[u] + 8 * c) * 2);
+            }
             {
                 // byte offsets 4*idx into the code table with one v_bfe_u32 per nibble (see gemm256.h)
                 const uint32_t wo = w & 0xF0F0F0F0u;
@@ -240,7 +250,10 @@ __global__ __launch_bounds__(256) void k_gemv4(const T *__restrict__ X, const ui
                 const f32x2 pr = f32x2{Lq[2 * j], Lq[2 * j + 1]} * f32x2{a[u][r], a[u][r]};  // two IEEE f32 products
                 const uint32_t wp = pack2<T>(pr[0], pr[1]);
 #pragma unroll
-                for (int i = 0; i < MT; i++) acc[r][i] = Dot2<T>::run(wp, xv[u][i][c][j], acc[r][i]);
+                for (int i = 0; i < MT; i++) {
+                    if constexpr (XLDS) acc[r][i] = Dot2<T>::run(wp, xq[q & 1][i][j], acc[r][i]);
+                    else acc[r][i] = Dot2<T>::run(wp, xv[u][i][c][j], acc[r][i]);
+                }
             }
         };
         lookup(std::integral_constant<int, 0>{}, L[0]);
@@ -265,6 +278,139 @@ __global__ __launch_bounds__(256) void k_gemv4(const T *__restrict__ X, const ui
 }
 
 // =====================================================================================
+// Skinny GEMM (2 <= M <= 64): the weight-streaming regime with more than a handful of activation rows.
+// One workgroup = 16 waves x 32 weight rows; wave w contracts the 128-k blocks w, w+16, ... of those rows with all
+// M activation rows on v_mfma_f32_16x16x32, so every packed weight is fetched and decoded exactly once (as in the
+// GEMV) while the M rows ride along in the MFMA's free dimension.  k is laid out so that lane quarter q of a
+// 128-k block owns k in [32q, 32q + 32): its 16 packed bytes are one load, the four dwords are the A fragments of
+// the block's four MFMAs, and the activation fragment of MFMA g is the 16 bytes at k = 32q + 8g.  The 16 partial
+// accumulators of a workgroup are added in wave order through LDS (deterministic), then bias and one rounding.
+// Needs K % 128 == 0, blocksize >= 32, 16-bit types.
+// =====================================================================================
+template <typename T> struct Mfma16;
+template <> struct Mfma16<f16_t> {
+    using frag = f16x8;
+    static __device__ __forceinline__ f32x4 run(frag a, frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+template <> struct Mfma16<bf16_t> {
+    using frag = bf16x8;
+    static __device__ __forceinline__ f32x4 run(frag a, frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+
+template <typename T, typename OutT, int QT, bool NESTED, int MT, int NR>
+__global__ __launch_bounds__(1024) void k_skinny4(const T *__restrict__ X, const uint8_t *__restrict__ packed, AbsmaxView am,
+                                                 const T *__restrict__ bias, OutT *__restrict__ out, int64_t M, int64_t N,
+                                                 int64_t K, int64_t K_weight, int bs_shift) {
+    constexpr int WV = 16;
+    __shared__ float lut[16];
+    extern __shared__ __attribute__((aligned(16))) char red_raw[];   // [WV][NR * MT][256] f32
+    float *red = reinterpret_cast<float *>(red_raw);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r16 = lane & 15, q = lane >> 4;
+    const int64_t n0 = (int64_t)blockIdx.x * (16 * NR);
+    const int64_t nblk = K_weight >> bs_shift, row_bytes = K_weight >> 1;
+    fill_code_lut<QT>(lut, threadIdx.x);
+
+    const uint8_t *wrow[NR];
+    int64_t arow[NR];
+#pragma unroll
+    for (int rg = 0; rg < NR; rg++) {
+        int64_t n = n0 + 16 * rg + r16;
+        n = n < N ? n : N - 1;
+        wrow[rg] = packed + n * row_bytes;
+        arow[rg] = n * nblk;
+    }
+    const T *xrow[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+        int64_t m = 16 * mt + r16;
+        m = m < M ? m : M - 1;
+        xrow[mt] = X + m * K;
+    }
+    f32x4 acc[NR][MT];
+#pragma unroll
+    for (int rg = 0; rg < NR; rg++)
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) acc[rg][mt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    const int64_t nb128 = K >> 7;
+    // packed weights + absmax of block b + WV are requested before block b is decoded (HBM latency); the activation
+    // fragments (L2-resident) are requested at the top of each trip
+    u32x4 w[NR], w_n[NR];
+    float a[NR], a_n[NR];
+    auto request_w = [&](int64_t b) {
+        const int64_t k_lane = (b << 7) + 32 * q;
+#pragma unroll
+        for (int rg = 0; rg < NR; rg++) {
+            w_n[rg] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(wrow[rg] + (k_lane >> 1)));
+            a_n[rg] = load_absmax<NESTED>(am, arow[rg] + (k_lane >> bs_shift));
+        }
+    };
+    if (wave < nb128) request_w(wave);
+    // raw barrier for the code table (__syncthreads() would drain the requests just issued)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    for (int64_t b = wave; b < nb128; b += WV) {
+        const int64_t k_lane = (b << 7) + 32 * q;
+        typename Mfma16<T>::frag xf[MT][4];
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+                xf[mt][g] = *reinterpret_cast<const typename Mfma16<T>::frag *>(xrow[mt] + k_lane + 8 * g);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int rg = 0; rg < NR; rg++) {
+            w[rg] = w_n[rg];
+            a[rg] = a_n[rg];
+        }
+        if (b + WV < nb128) request_w(b + WV);
+        __builtin_amdgcn_sched_barrier(0);   // every request of the block is in flight before the first use
+#pragma unroll
+        for (int rg = 0; rg < NR; rg++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                // the reference's dequantize arithmetic: code * absmax in f32 -> RNE 16 bit (functional.py:388-416)
+                const uint32_t wd = w[rg][g];
+                const uint32_t wo = wd & 0xF0F0F0F0u;
+                const uint32_t we = (wd << 2) & 0x3C3C3C3Cu;
+                const char *lutb = reinterpret_cast<const char *>(lut);
+                u32x4 fr;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const float lo = *reinterpret_cast<const float *>(lutb + bfe_u32(we, 8 * j, 8)) * a[rg];
+                    const float hi = *reinterpret_cast<const float *>(lutb + bfe_u32(wo, 8 * j + 2, 6)) * a[rg];
+                    fr[j] = pack2<T>(lo, hi);
+                }
+                const auto af = __builtin_bit_cast(typename Mfma16<T>::frag, fr);
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++) acc[rg][mt] = Mfma16<T>::run(af, xf[mt][g], acc[rg][mt]);
+            }
+    }
+    // ---- reduce the WV partial 16 x 16 tiles in wave order
+#pragma unroll
+    for (int rg = 0; rg < NR; rg++)
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+            *reinterpret_cast<f32x4 *>(red + ((wave * (NR * MT) + rg * MT + mt) * 256 + lane * 4)) = acc[rg][mt];
+    __syncthreads();
+    for (int t = threadIdx.x; t < NR * MT * 256; t += 1024) {
+        const int tile = t >> 8, e = t & 255;
+        float s = 0.0f;
+#pragma unroll
+        for (int wv = 0; wv < WV; wv++) s += red[(wv * (NR * MT) + tile) * 256 + e];
+        const int ln = e >> 2, r = e & 3;
+        const int rg = tile / MT, mt = tile % MT;
+        const int64_t n = n0 + 16 * rg + 4 * (ln >> 4) + r;   // D[a][b]: a = 4 * (lane >> 4) + r (weight row), b = lane & 15
+        const int64_t m = 16 * mt + (ln & 15);
+        if (n < N && m < M) {
+            const float v = s + (bias ? to_f32(bias[n]) : 0.0f);
+            out[m * N + n] = from_f32<OutT>(to_f32(from_f32<T>(v)));
+        }
+    }
+}
+
+// =====================================================================================
 // dispatch
 // =====================================================================================
 static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -272,6 +418,29 @@ static inline int ilog2(int v) {
     int s = 0;
     while ((1 << s) < v) s++;
     return s;
+}
+
+// Split-K workspace handed in by mbnb_matmul_4bit_ws for the duration of one call (thread-local: the library keeps
+// no other per-call state; nullptr = no split-K).
+static thread_local float *tls_ws = nullptr;
+static thread_local int64_t tls_ws_bytes = 0;
+void set_matmul4_workspace(void *ws, int64_t bytes) {
+    tls_ws = static_cast<float *>(ws);
+    tls_ws_bytes = bytes;
+}
+
+// Number of K slices for the 128 x 128 kernel: enough workgroups for two per CU, at least four k-steps (256 k) per
+// slice.  1 = no split.  Shared by the dispatcher and mbnb_matmul_4bit_workspace_bytes.
+int64_t matmul4_splitk_slices(int64_t M, int64_t N, int64_t K) {
+    if (M <= 4 || K % 64 != 0) return 1;
+    const int64_t tiles256 = ((M + 255) / 256) * ((N + 255) / 256);
+    if (tiles256 >= 96) return 1;                      // served by the 256 x 256 kernel
+    const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
+    int64_t s = (512 + tiles - 1) / tiles;
+    const int64_t smax = K / 256;
+    if (s > smax) s = smax;
+    if (s > 16) s = 16;
+    return s < 2 ? 1 : s;
 }
 
 template <typename T, typename OutT, int QT, bool NESTED>
@@ -284,7 +453,15 @@ static int launch_matmul4(const void *A, int64_t M, int64_t K, const uint8_t *pa
     const bool fast_layout = is16 && blocksize >= 32 && (K_weight % 32 == 0) && (K % 8 == 0) && aligned16(A) &&
                              aligned16(packed);
     if constexpr (is16) {
-        if (fast_layout && M <= 16 && (K % 32 == 0)) {
+        const int64_t slices = matmul4_splitk_slices(M, N, K);
+        const bool splitk = fast_layout && slices > 1 && tls_ws != nullptr && ((reinterpret_cast<uintptr_t>(tls_ws) & 15) == 0) &&
+                            tls_ws_bytes >= slices * ((M + 127) / 128) * ((N + 127) / 128) * 65536;   // full 128 x 128 f32 tiles
+        static const bool no_skinny = getenv("MBNB_NO_SKINNY") != nullptr;   // debug A/B switch
+        // weight-streaming regime with a few activation rows: 2 <= M <= 32, and up to 64 for layers of <= 16 Mi weights
+        // (beyond that the activation re-reads of the skinny kernel cost more than split-K's second pass)
+        const bool skinny = fast_layout && !no_skinny && M >= 2 && (M <= 32 || (M <= 64 && N * K <= ((int64_t)1 << 24))) &&
+                            (K % 128 == 0);
+        if (fast_layout && M <= 16 && (K % 32 == 0) && !(splitk && M > 4) && !skinny) {
             const int sh = ilog2(blocksize);
             const int64_t Kp = (K + 2047) & ~(int64_t)2047;
             const bool xlds = (int64_t)8 * Kp * 2 <= 65536;  // largest MT rows fit the default dynamic-LDS limit
@@ -302,12 +479,42 @@ static int launch_matmul4(const void *A, int64_t M, int64_t K, const uint8_t *pa
             // weights in flight per wave: +12 % streaming rate at N >= 8192, tools/gemv_sweep.py)
             if (M == 1 && N >= 8192) MBNB_GEMV(1, 2, 2);
             else if (M == 1) MBNB_GEMV(1, 1, 2);
-            else if (M == 2) MBNB_GEMV(2, 1, 2);
-            else if (M <= 4) MBNB_GEMV(4, 2, 1);
-            else MBNB_GEMV(8, 1, 1);
+            else if (!xlds) {           // activations in registers: keep the register-light shapes
+                if (M == 2) MBNB_GEMV(2, 1, 2);
+                else if (M <= 4) MBNB_GEMV(4, 2, 1);
+                else MBNB_GEMV(8, 1, 1);
+            } else if (M == 2) MBNB_GEMV(2, 1, 2);
+            else if (M <= 4) MBNB_GEMV(4, 1, 2);
+            else MBNB_GEMV(8, 1, 2);
 #undef MBNB_GEMV
             set_kernel_name("gemv");
             return check_launch("matmul_4bit(gemv)");
+        }
+        if (skinny) {
+            const int sh = ilog2(blocksize);
+#define MBNB_SKINNY(MT, NR)                                                                                          \
+    do {                                                                                                             \
+        constexpr int lds = 16 * NR * MT * 1024;                                                                     \
+        auto kern = k_skinny4<T, OutT, QT, NESTED, MT, NR>;                                                          \
+        if (lds > 65536) {                                                                                           \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                 \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);                     \
+            if (e != hipSuccess) {                                                                                   \
+                set_error("matmul_4bit: hipFuncSetAttribute(skinny) failed: %s", hipGetErrorString(e));              \
+                return (int)e;                                                                                       \
+            }                                                                                                        \
+        }                                                                                                            \
+        hipLaunchKernelGGL(kern, dim3((unsigned)((N + 16 * NR - 1) / (16 * NR))), dim3(1024), lds, st, x, packed, am, b, o, M, N, \
+                           K, K_weight, sh);                                                                         \
+    } while (0)
+            // one 16-row group per workgroup (N / 16 workgroups): measured faster than two at every shape tried
+            // (tools/m_sweep2.py), the extra activation traffic notwithstanding
+            if (M <= 16) MBNB_SKINNY(1, 1);
+            else if (M <= 32) MBNB_SKINNY(2, 1);
+            else MBNB_SKINNY(4, 1);
+#undef MBNB_SKINNY
+            set_kernel_name("skinny_mfma16");
+            return check_launch("matmul_4bit(skinny)");
         }
         if (fast_layout && (K % 64 == 0) && ((M + 255) / 256) * ((N + 255) / 256) >= 96) {
             // large problems: 256 x 256 tiles, one workgroup per CU
@@ -396,7 +603,18 @@ static int launch_matmul4(const void *A, int64_t M, int64_t K, const uint8_t *pa
                 }
                 attr_done = true;
             }
-            hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, st, x, wp, b, o, M, N, K);
+            if (splitk) {
+                // k slices of whole 64-k steps, the last one takes the remainder
+                int64_t kps = (((K / 64) + slices - 1) / slices) * 64;
+                hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)slices), dim3(256), lds, st, x, wp, b, o, M, N, K, tls_ws, kps);
+                int rc = check_launch("matmul_4bit(mfma128 split-K)");
+                if (rc) return rc;
+                hipLaunchKernelGGL((k_splitk_reduce<T, OutT>), dim3((unsigned)(tiles * 16)), dim3(256), 0, st, tls_ws, (int)slices,
+                                   b, o, M, N, (M + BM - 1) / BM, tiles);
+                set_kernel_name("mfma128_splitk");
+                return check_launch("matmul_4bit(split-K reduce)");
+            }
+            hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, st, x, wp, b, o, M, N, K, static_cast<float *>(nullptr), (int64_t)0);
             set_kernel_name("mfma128");
             return check_launch("matmul_4bit(mfma128)");
         }

@@ -486,11 +486,15 @@ def matmul_4bit(
     out = torch.empty(M, N, dtype=out_dtype, device=A.device)
     keep: list = []
     desc = _absmax_desc(quant_state.absmax.to(A.device), quant_state.state2, keep)
+    # mid-sized M leaves too few output tiles for 256 CUs: the library then splits K over a caller-provided f32
+    # workspace (0 bytes = not needed for this shape); torch's caching allocator makes the allocation a pointer bump
+    ws_bytes = int(_native.lib().mbnb_matmul_4bit_workspace_bytes(M, N, K))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=A.device) if ws_bytes > 0 else None
     with torch.cuda.device(A.device):
-        check(_native.lib().mbnb_matmul_4bit(
+        check(_native.lib().mbnb_matmul_4bit_ws(
             ptr(A2), M, K, ptr(packed), ctypes.byref(desc), N, K_weight, int(blocksize),
             _native.QUANT_CODE[quant_state.quant_type], w_code, ptr(bias_w), _native.DTYPE_CODE[out_dtype],
-            ptr(out), stream_ptr(A.device)), "matmul_4bit")
+            ptr(out), ptr(ws), ws_bytes, stream_ptr(A.device)), "matmul_4bit")
     if out_dtype != compute_dtype:
         out = out.to(compute_dtype)
     return out.reshape(*orig_shape[:-1], N)

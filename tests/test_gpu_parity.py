@@ -146,7 +146,37 @@ def _oracle_vs_gpu_matmul(M, N, K, dt, qt="nf4", bs=64, cs=False, bias=True, cd=
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("M", [1, 2, 3, 5, 8, 13, 16])
 def test_matmul_gemv_path(M, dt):
-    assert _oracle_vs_gpu_matmul(M, 512, 1024, dt, seed=10 + M) == "gemv"
+    """Weight-streaming shapes: M = 1 -> wave-per-row GEMV; 2 <= M <= 32 -> skinny MFMA (16x16x32) kernel."""
+    assert _oracle_vs_gpu_matmul(M, 512, 1024, dt, seed=10 + M) == ("gemv" if M == 1 else "skinny_mfma16")
+
+
+@pytest.mark.parametrize("case", [
+    dict(M=2, N=4096, K=4096, dt=torch.bfloat16), dict(M=7, N=1000, K=384, dt=torch.float16, qt="fp4", cs=True),
+    dict(M=16, N=11008, K=4096, dt=torch.bfloat16, cs=True), dict(M=17, N=48, K=128, dt=torch.float16, bs=32),
+    dict(M=32, N=4096, K=1024, dt=torch.float16, cd=torch.float32), dict(M=33, N=512, K=256, dt=torch.bfloat16),
+    dict(M=64, N=4096, K=4096, dt=torch.bfloat16, bs=128),
+])
+def test_matmul_skinny_path(case):
+    """k_skinny4: 1, 2 and 4 activation tiles of 16 rows, ragged N, nested absmax, both code tables, 1-2 blocks per wave."""
+    c = dict(case)
+    assert _oracle_vs_gpu_matmul(c.pop("M"), c.pop("N"), c.pop("K"), c.pop("dt"), seed=27, **c) == "skinny_mfma16"
+
+
+@pytest.mark.parametrize("case", [
+    dict(M=96, N=4096, K=4096, dt=torch.bfloat16), dict(M=200, N=1000, K=1024, dt=torch.float16, cs=True, qt="fp4"),
+    dict(M=512, N=4096, K=2048, dt=torch.bfloat16, cd=torch.float32), dict(M=1024, N=2048, K=4096, dt=torch.float16),
+    dict(M=40, N=11008, K=4096, dt=torch.bfloat16, cs=True),
+])
+def test_matmul_splitk_path(case):
+    """128 x 128 tiles with K split over a caller workspace (mbnb_matmul_4bit_ws) and a deterministic slice reduction."""
+    c = dict(case)
+    M, N, K = c["M"], c["N"], c["K"]
+    assert _oracle_vs_gpu_matmul(c.pop("M"), c.pop("N"), c.pop("K"), c.pop("dt"), seed=28, **c) == "mfma128_splitk"
+    # run-to-run determinism (fixed slice order, no atomics)
+    W = synthetic.normal((N, K), torch.bfloat16, seed=1, std=0.05).to(DEV)
+    x = synthetic.normal((M, K), torch.bfloat16, seed=2).to(DEV)
+    packed, st = bnb.quantize_nf4(W)
+    assert torch.equal(bnb.matmul_4bit(x, packed, st), bnb.matmul_4bit(x, packed, st))
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
@@ -253,10 +283,11 @@ def test_matmul_row_independence_and_linearity_full_size():
     Yh = bnb.matmul_4bit(X * 0.5, packed, st)
     big = Y.abs() > 1e-2
     assert torch.equal((Yh * 2)[big], Y[big])
-    # GEMV kernel on 4 of the rows
-    yg = bnb.matmul_4bit(X[:4], packed, st)
-    assert _native.last_kernel() == "gemv"
-    assert rel_fro(yg, Y[:4]) <= TOL[torch.float16]
+    # the same rows through the other kernels: GEMV (1 row), skinny MFMA (4 and 24 rows), split-K (300 rows)
+    for rows_n, kern in ((1, "gemv"), (4, "skinny_mfma16"), (24, "skinny_mfma16"), (300, "mfma128_splitk")):
+        yg = bnb.matmul_4bit(X[:rows_n], packed, st)
+        assert _native.last_kernel() == kern
+        assert rel_fro(yg, Y[:rows_n]) <= TOL[torch.float16]
 
 
 def test_matmul_config_b_double_quant_full_size():

@@ -13,7 +13,7 @@ def timeit(fn, n=50):
     e1.record(); e1.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
 for (N, K) in [(4096, 4096), (11008, 4096), (4096, 11008), (28672, 8192), (65536, 8192)]:
-    for M in (1, 4):
+    for M in (1, 2, 4, 8, 16):
         W = torch.randn(N, K, device=dev, dtype=torch.float16)
         packed, st = bnb.quantize_nf4(W); del W
         x = torch.randn(M, K, device=dev, dtype=torch.float16)
