@@ -17,10 +17,10 @@ os.makedirs(dst, exist_ok=True)
 
 
 def stats(name, cmd, out):
-    files = glob.glob(os.path.join(src, f"{tag}_{name}", "*", "*kernel_stats.csv"))
+    files = sorted(glob.glob(os.path.join(src, f"{tag}_{name}", "*", "*kernel_stats.csv")), key=os.path.getmtime)
     if not files:
         return
-    rows = list(csv.DictReader(open(files[0])))
+    rows = list(csv.DictReader(open(files[-1])))   # newest run
     with open(os.path.join(dst, out), "w") as o:
         o.write(f"# rocprofv3 --kernel-trace --stats --output-format csv -- {cmd}   (MI355X; kernel names truncated to 110 chars)\n")
         o.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs,StdDev\n")
@@ -35,7 +35,7 @@ stats("int8_4096", "python3 bench.py --workload int8_4096 --no-cpu-baseline --st
 
 res, dur = {}, []
 for name in ("fetch", "write", "tcc", "sq", "lds"):
-    files = glob.glob(os.path.join(src, f"{tag}_{name}", "*", "*counter_collection.csv"))
+    files = sorted(glob.glob(os.path.join(src, f"{tag}_{name}", "*", "*counter_collection.csv")), key=os.path.getmtime)[-1:]
     if not files:
         continue
     agg = collections.defaultdict(list)
