@@ -385,6 +385,27 @@ def main():
                            "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                         "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None}}
             del layers
+        if not args.no_gemv:
+            # batch sizes between the two metric shapes (the reference's native path serves M <= 512): one HIP graph of
+            # 8 calls per M, same weight; which kernel served it is recorded next to the time
+            sweep = []
+            for Ms in (2, 16, 64, 256, 1024):
+                xs_ = torch.randn(Ms, K, generator=g, device=dev, dtype=torch.float32).to(dt)
+                gr = torch.cuda.CUDAGraph()
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    bnb.matmul_4bit(xs_, packed, state)
+                    with torch.cuda.graph(gr, stream=side):
+                        for _ in range(8):
+                            bnb.matmul_4bit(xs_, packed, state)
+                torch.cuda.current_stream().wait_stream(side)
+                for _ in range(3):
+                    gr.replay()
+                torch.cuda.synchronize()
+                us = event_time_ms(gr.replay, 10) / 8 * 1e3
+                sweep.append({"M": Ms, "us": round(us, 2), "kernel": _native.last_kernel()})
+            out["batch_sweep"] = sweep
         if not args.no_empirical:
             # Empirical ceilings of this box next to the vendor peaks: the vendor BLAS on the same
             # 4096^3 bf16 problem with the weight already dequantised (torch.matmul -> hipBLASLt/rocBLAS; context

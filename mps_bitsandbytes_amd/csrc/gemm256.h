@@ -815,6 +815,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm256p(const T *__restrict__ X, ty
         }
 }
 
+#ifdef MBNB_ABLATION   // measured schedule alternatives: diagnostic builds only (make EXTRA=-DMBNB_ABLATION)
 // =====================================================================================
 // k_gemm256v — slot-pinned k-step with the decode done entirely on the VALU (gen_kstep.py valu):
 // per thread and tile a 16-entry table of RNE16(code[i] * absmax) is built (16 v_mul + 8 cvt_pk) and split
@@ -1508,6 +1509,8 @@ __global__ __launch_bounds__(512, 2) void k_gemm256pp(const T *__restrict__ X, t
             }
         }
 }
+
+#endif  // MBNB_ABLATION
 
 template <bool NESTED> constexpr int gemm256p_lds_bytes() {
     // stages + two raw slots + the absmax-by-4 slots of the AM4 variants (plain: 2 x 4 KiB, double-quantised: 2 x 2 KiB)

@@ -525,27 +525,24 @@ static int launch_matmul4(const void *A, int64_t M, int64_t K, const uint8_t *pa
             const int64_t tiles = ((M + 255) / 256) * ((N + 255) / 256);
             int od = sizeof(OutT) == 4 ? MBNB_F32 : (std::is_same<OutT, f16_t>::value ? MBNB_F16 : MBNB_BF16);
             if (bs2_pow2) {
-                static const bool use_pp = getenv("MBNB_PINGPONG") != nullptr;  // debug A/B switch (default: lockstep schedule, faster as measured)
                 using KernT = void (*)(const T *, typename P::Params, const T *, void *, int, int64_t, int64_t, int64_t);
-                                static const bool use_valu = getenv("MBNB_VALUDEC") != nullptr;  // debug A/B switch: slot-pinned + VALU decode
-                // production: k_gemm256p with the byte-table decode; plain f32 absmax at blocksize 64 additionally
-                // fetches absmax once per four k-steps (AM4).  The other variants are kept as measured alternatives.
-                static const bool no_blut = getenv("MBNB_NO_BLUT") != nullptr;  // debug A/B switch: 16-entry table decode
-                KernT kern = use_valu ? k_gemm256v<T, NESTED>
-                                      : (use_pp ? k_gemm256pp<T, NESTED>
-                                                : (no_blut ? k_gemm256p<T, NESTED> : k_gemm256p<T, NESTED, 0, false, true>));
-                static const bool no_am4 = getenv("MBNB_NO_AM4") != nullptr;  // debug A/B switch
-                if constexpr (!NESTED) {
-                    if (!no_am4 && !use_pp && blocksize == 64 && (K_weight % 256 == 0)) {
-                        if (use_valu) kern = k_gemm256v<T, false, 0, true>;
-                        else kern = no_blut ? k_gemm256p<T, false, 0, true> : k_gemm256p<T, false, 0, true, true>;
-                    }
-                } else {
-                    // double-quantised absmax: four int8 codes (one aligned dword) + their shared absmax2 per four k-steps
-                    if (!no_am4 && !use_pp && !use_valu && blocksize == 64 && (K_weight % 256 == 0) && am.bs2 >= 4 &&
-                        (reinterpret_cast<uintptr_t>(am.i8) & 3) == 0)
-                        kern = no_blut ? k_gemm256p<T, true, 0, true> : k_gemm256p<T, true, 0, true, true>;
-                }
+                // k_gemm256p with the byte-table decode; at blocksize 64 the absmax (plain f32, or int8 codes + absmax2)
+                // is fetched once per four k-steps (AM4).  MBNB_NO_BLUT / MBNB_NO_AM4: A/B switches for those two.
+                static const bool no_blut = getenv("MBNB_NO_BLUT") != nullptr;
+                static const bool no_am4 = getenv("MBNB_NO_AM4") != nullptr;
+                KernT kern = no_blut ? k_gemm256p<T, NESTED> : k_gemm256p<T, NESTED, 0, false, true>;
+                bool am4 = !no_am4 && blocksize == 64 && (K_weight % 256 == 0);
+                if constexpr (NESTED) am4 = am4 && am.bs2 >= 4 && (reinterpret_cast<uintptr_t>(am.i8) & 3) == 0;
+                if (am4) kern = no_blut ? k_gemm256p<T, NESTED, 0, true> : k_gemm256p<T, NESTED, 0, true, true>;
+#ifdef MBNB_ABLATION
+                // diagnostic builds: the measured schedule alternatives
+                static const bool use_pp = getenv("MBNB_PINGPONG") != nullptr;    // ping-pong schedule
+                static const bool use_valu = getenv("MBNB_VALUDEC") != nullptr;   // slot-pinned + VALU decode
+                if (use_pp) kern = k_gemm256pp<T, NESTED>;
+                if (use_valu) kern = (!NESTED && am4) ? k_gemm256v<T, NESTED, 0, !NESTED> : k_gemm256v<T, NESTED>;
+#else
+                constexpr bool use_pp = false;
+#endif
 #ifdef MBNB_ABLATION
                 if constexpr (std::is_same<T, bf16_t>::value && !NESTED) {
                     static const int abl = getenv("MBNB_ABLATE") ? atoi(getenv("MBNB_ABLATE")) : 0;

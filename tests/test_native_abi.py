@@ -47,6 +47,26 @@ def test_argument_errors_use_status_and_last_error():
     assert lib.mbnb_matmul_int8(None, None, None, None, 0, 16, 16, 0, None, None, None) == 0
     with pytest.raises(RuntimeError, match="status -1"):
         _native.check(-1, "unit")
+    # the nn entry points validate before touching the device too
+    assert lib.mbnb_embedding_4bit(None, 4, None, None, 10, 15, 64, 0, 0, 0, 0, None, None) == -1 and b"even" in lib.mbnb_last_error()
+    assert lib.mbnb_embedding_4bit(None, 0, None, None, 10, 16, 64, 0, 0, 0, 0, None, None) == 0
+    assert lib.mbnb_embedding_8bit(None, 4, None, None, 10, 16, 0, 0, 0, None, None) == -1
+    assert lib.mbnb_outlier_linear(None, 0, 4, 64, None, None, 8, None, 2, None, None, None, None, None) == -1
+
+
+def test_workspace_size_functions_are_pure_host_code():
+    """Split-K policy (mbnb_matmul_4bit_workspace_bytes): no workspace for GEMV / skinny-sized M or for shapes that
+    fill the chip with 256 x 256 tiles; slices x tiles x 64 KiB (128 x 128 f32) in between."""
+    lib = _native.lib()
+    assert lib.mbnb_matmul_4bit_workspace_bytes(1, 4096, 4096) == 0
+    assert lib.mbnb_matmul_4bit_workspace_bytes(4, 4096, 4096) == 0
+    assert lib.mbnb_matmul_4bit_workspace_bytes(4096, 4096, 4096) == 0           # 256 tiles of 256^2
+    assert lib.mbnb_matmul_4bit_workspace_bytes(128, 4096, 4096) == 16 * 32 * 65536   # 32 tiles -> 16 slices of 256 k
+    assert lib.mbnb_matmul_4bit_workspace_bytes(1024, 4096, 4096) == 2 * 256 * 65536
+    assert lib.mbnb_matmul_4bit_workspace_bytes(128, 4096, 72) == 0               # K % 64 != 0
+    assert lib.mbnb_matmul_4bit_workspace_bytes(0, 4096, 4096) == 0
+    assert lib.mbnb_outlier_linear_workspace_bytes(4096, 4096) == 4096 * 4096 + 4 * 4096
+    assert lib.mbnb_outlier_linear_workspace_bytes(3, 5) == 256 + 256
 
 
 def test_product_has_no_cpu_path_and_never_imports_the_oracle():
