@@ -47,6 +47,8 @@ def parse():
                     help="nf4_m4096 = the BASELINE metric (default); nf4dq_ffn / int8_4096 / nf4_m1 = BASELINE configs 3, 4, 2; "
                          "embed4 / embed8 / outlier = the SURVEY 8f rank-3 rows (single GPU)")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the output all-gather (GEMM-only scaling)")
+    ap.add_argument("--sync-gather", action="store_true", help="N>1: blocking all-gather after every GEMM (no overlap); "
+                    "with --no-gather and the default these are the three curves of SURVEY 8e")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemv", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
@@ -271,7 +273,10 @@ def main():
                     counter[0] += 1
                     if pending[i] is not None:
                         pending[i].wait()
-                    pending[i] = dist.all_gather_into_tensor(gathered[i], y, async_op=True)
+                    if args.sync_gather:
+                        dist.all_gather_into_tensor(gathered[i], y)
+                    else:
+                        pending[i] = dist.all_gather_into_tensor(gathered[i], y, async_op=True)
             flops_per_step = 2.0 * M * N * K
     else:
         A = torch.randint(-127, 128, (M, K), generator=g, device=dev, dtype=torch.int8)
@@ -323,7 +328,7 @@ def main():
                                   "int8_4096": "rowwise INT8 matmul_int8 4096x4096x4096 on int8 MFMA",
                                   "nf4_m1": "fused NF4 dequant+GEMV, weight 4096x4096 fp16 bs64, M=1, rotating over 64 layers"}[wl],
                      "global_rows": M_global, "rows_per_gpu": M, "N": N, "K": K,
-                     "parallelism": f"rows sharded x{world}, weights replicated" + (", all-gather of outputs (RCCL, async: overlaps the next step's GEMM)" if gathered is not None else ""),
+                     "parallelism": f"rows sharded x{world}, weights replicated" + ((", all-gather of outputs (RCCL, blocking)" if args.sync_gather else ", all-gather of outputs (RCCL, async: overlaps the next step's GEMM)") if gathered is not None else ""),
                      "kernel": kernel_name}
     if wl == "nf4_m1":
         gbs = bytes_per_launch / (kern_ms * 1e-3) / 1e9
