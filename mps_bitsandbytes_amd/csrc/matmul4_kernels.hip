@@ -436,7 +436,7 @@ int64_t matmul4_splitk_slices(int64_t M, int64_t N, int64_t K) {
     const int64_t tiles256 = ((M + 255) / 256) * ((N + 255) / 256);
     if (tiles256 >= 96) return 1;                      // served by the 256 x 256 kernel
     const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
-    int64_t s = (512 + tiles - 1) / tiles;
+    int64_t s = (512 + tiles - 1) / tiles;   // 512 workgroups: best of {256, 512, 768, 1024} at M = 128 ... 1024 (4096^2)
     const int64_t smax = K / 256;
     if (s > smax) s = smax;
     if (s > 16) s = 16;
