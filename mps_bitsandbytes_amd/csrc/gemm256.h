@@ -301,8 +301,8 @@ constexpr int P_IMG = 32768;  // bytes per image stage
 // its private 16 KiB of (now idle) LDS turns that into 16-byte stores of whole 256-byte row segments.
 // 16-bit outputs only; fp32 output keeps the direct stores.
 // ---------------------------------------------------------------------------------------------
-template <typename T, typename OutT>
-__device__ __forceinline__ void epilogue_staged(const f32x16 (&acc)[4][2], char *wave_lds, const T *__restrict__ bias,
+template <typename T, typename OutT, int NJ = 2, int J0 = 0>
+__device__ __forceinline__ void epilogue_staged(const f32x16 (&acc)[4][NJ], char *wave_lds, const T *__restrict__ bias,
                                                 OutT *__restrict__ out, int64_t M, int64_t N, int64_t m_base,
                                                 int64_t n_base, int lane) {
     static_assert(sizeof(OutT) == 2, "staged epilogue is for 16-bit outputs");
@@ -318,13 +318,14 @@ __device__ __forceinline__ void epilogue_staged(const f32x16 (&acc)[4][2], char 
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
-                    float s = acc[i][j][4 * g + e];
+                    float s = acc[i][J0 + j][4 * g + e];
                     const int64_t n = n_base + nl + e;
                     if (bias != nullptr && n < N) s += to_f32(bias[n]);
                     v[e] = to_f32(from_f32<T>(s));  // one rounding to the compute dtype
                 }
                 *reinterpret_cast<u32x2 *>(wave_lds + (j * 32 + fr) * ROWB + nl * 2) =
                     u32x2{pack2<OutT>(v[0], v[1]), pack2<OutT>(v[2], v[3])};
+                if constexpr (NJ > 2) __builtin_amdgcn_sched_barrier(0);   // 256-accumulator kernels: bound the live range of the reads
             }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private tile: no barrier needed
     const bool vec_ok = (N % 8 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);

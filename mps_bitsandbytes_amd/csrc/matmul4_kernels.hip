@@ -16,6 +16,9 @@
 #include <utility>
 
 #include "gemm256.h"
+#ifdef MBNB_ABLATION
+#include "gemm256q.h"   // four-wave variant (work in progress, see its header): diagnostic builds only
+#endif
 
 namespace mbnb {
 
@@ -536,6 +539,19 @@ static int launch_matmul4(const void *A, int64_t M, int64_t K, const uint8_t *pa
                 if (am4) kern = no_blut ? k_gemm256p<T, NESTED, 0, true> : k_gemm256p<T, NESTED, 0, true, true>;
 #ifdef MBNB_ABLATION
                 // diagnostic builds: the measured schedule alternatives
+                static const bool use_q = getenv("MBNB_Q4W") != nullptr;   // A/B switch: four-wave variant (gemm256q.h)
+                if (use_q && am4) {
+                    auto kq = k_gemm256q<T, NESTED>;
+                    constexpr int ldsq = gemm256q_lds_bytes<NESTED>();
+                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kq), hipFuncAttributeMaxDynamicSharedMemorySize, ldsq);
+                    if (e != hipSuccess) {
+                        set_error("matmul_4bit: hipFuncSetAttribute(256q) failed: %s", hipGetErrorString(e));
+                        return (int)e;
+                    }
+                    hipLaunchKernelGGL(kq, dim3((unsigned)tiles), dim3(256), ldsq, st, x, wp, b, static_cast<void *>(o), od, M, N, K);
+                    set_kernel_name("mfma256q");
+                    return check_launch("matmul_4bit(mfma256q)");
+                }
                 static const bool use_pp = getenv("MBNB_PINGPONG") != nullptr;    // ping-pong schedule
                 static const bool use_valu = getenv("MBNB_VALUDEC") != nullptr;   // slot-pinned + VALU decode
                 if (use_pp) kern = k_gemm256pp<T, NESTED>;
