@@ -5,6 +5,7 @@
 //   linear_int8  16-bit activations x int8 weights decoded in the B-tile producer (gemm_tile.h)
 //                (reference: Linear8bit.forward nn/linear8bit.py:70-102; Metal int8_matmul_simd mm:203-305)
 #include "gemm256.h"
+#include "gemm256w.h"
 
 namespace mbnb {
 
@@ -440,6 +441,22 @@ static int launch_linear_int8(const void *X, int64_t M, int64_t K, const int8_t 
             // weight-tile producer (gemm256.h, k_gemm256)
             using P = I8ProducerRT<T>;
             typename P::Params wp{W, scales, N, K};
+            const int64_t tiles = ((M + 255) / 256) * ((N + 255) / 256);
+            const int od = std::is_same<T, f16_t>::value ? MBNB_F16 : MBNB_BF16;
+            static const bool old_w8 = getenv("MBNB_W8_REGSTAGED") != nullptr;   // A/B switch: register-staged k_gemm256
+            if (!old_w8 && ((reinterpret_cast<uintptr_t>(W) & 15) == 0)) {
+                // LDS-DMA pipeline (gemm256w.h): activations and raw int8 weights by global_load_lds
+                auto kw = k_gemm256w<T>;
+                constexpr int ldsw = gemm256w_lds_bytes();
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kw), hipFuncAttributeMaxDynamicSharedMemorySize, ldsw);
+                if (e != hipSuccess) {
+                    set_error("linear_int8: hipFuncSetAttribute(256w) failed: %s", hipGetErrorString(e));
+                    return (int)e;
+                }
+                hipLaunchKernelGGL(kw, dim3((unsigned)tiles), dim3(512), ldsw, st, x, wp, b, static_cast<void *>(o), od, M, N, K);
+                set_kernel_name("w8a16_mfma256");
+                return check_launch("linear_int8(mfma256w)");
+            }
             auto kern = k_gemm256<T, P>;
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS);
@@ -447,8 +464,6 @@ static int launch_linear_int8(const void *X, int64_t M, int64_t K, const int8_t 
                 set_error("linear_int8: hipFuncSetAttribute(256) failed: %s", hipGetErrorString(e));
                 return (int)e;
             }
-            const int64_t tiles = ((M + 255) / 256) * ((N + 255) / 256);
-            const int od = std::is_same<T, f16_t>::value ? MBNB_F16 : MBNB_BF16;
             hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(512), G256_LDS, st, x, wp, b, static_cast<void *>(o), od, M, N, K);
             set_kernel_name("w8a16_mfma256");
             return check_launch("linear_int8(mfma256)");
