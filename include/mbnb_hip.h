@@ -159,6 +159,12 @@ int mbnb_matmul_int8(const int8_t *A, const int8_t *B, const float *A_scales,
 int mbnb_linear_int8(const void *X, int dtype, int64_t M, int64_t K, const int8_t *W,
                      const float *W_scales, int64_t N, const void *bias, void *out, void *stream);
 
+/* linear_int8 with a split-K workspace of mbnb_matmul_4bit_workspace_bytes(M, N, K) bytes (the policy is shared with
+ * the 4-bit path; 0 = not needed).  workspace == NULL behaves exactly like mbnb_linear_int8. */
+int mbnb_linear_int8_ws(const void *X, int dtype, int64_t M, int64_t K, const int8_t *W,
+                        const float *W_scales, int64_t N, const void *bias, void *out, void *workspace,
+                        int64_t workspace_bytes, void *stream);
+
 /* ---------------------------------------------------------------------------
  * embedding_4bit — replaces `_C.embedding_4bit_nf4` / `_C.embedding_4bit_fp4` (host mm:2309-2388, kernels
  * mm:1213-1275, bindings :2765-2770) with the numerics of Embedding4bit.forward's Python path

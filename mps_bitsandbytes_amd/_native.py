@@ -56,6 +56,8 @@ _SIGNATURES = {
                                  c_void_p, c_void_p, c_void_p]),
     "mbnb_linear_int8": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
                                  c_void_p, c_void_p]),
+    "mbnb_linear_int8_ws": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
+                                    c_void_p, c_void_p, c_int64, c_void_p]),
     "mbnb_embedding_4bit": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int,
                                     c_int64, c_int, c_void_p, c_void_p]),
     "mbnb_embedding_8bit": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int64, c_int,

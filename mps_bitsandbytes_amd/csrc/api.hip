@@ -38,6 +38,7 @@ int dequantize_rowwise_dispatch(const int8_t *, const float *, int64_t, int64_t,
 int double_quant_dispatch(const void *, int, int64_t, int64_t, int8_t *, int8_t *, float *, float *, int, int, hipStream_t);
 int matmul_4bit_dispatch(const void *, int64_t, int64_t, const uint8_t *, const AbsmaxView &, int64_t, int64_t, int, int, int, const void *, int, void *, hipStream_t);
 void set_matmul4_workspace(void *, int64_t);
+void set_linear8_workspace(void *, int64_t);
 int64_t matmul4_splitk_slices(int64_t, int64_t, int64_t);
 int matmul_int8_dispatch(const int8_t *, const int8_t *, const float *, const float *, int64_t, int64_t, int64_t, int, void *, void *, hipStream_t);
 int linear_int8_dispatch(const void *, int, int64_t, int64_t, const int8_t *, const float *, int64_t, const void *, void *, hipStream_t);
@@ -253,6 +254,14 @@ int mbnb_outlier_linear(const void *X, int dtype, int64_t M, int64_t K, const in
     if (n_outliers > 0 && (!outlier_idx || !outlier_w)) return fail(MBNB_ERR_ARG, "outlier_linear: outliers without index/weight buffers");
     return outlier_linear_dispatch(X, dtype, M, K, W, W_scales, N, outlier_idx, n_outliers, outlier_w, bias, out, workspace,
                                    static_cast<hipStream_t>(stream));
+}
+
+int mbnb_linear_int8_ws(const void *X, int dtype, int64_t M, int64_t K, const int8_t *W, const float *W_scales, int64_t N,
+                        const void *bias, void *out, void *workspace, int64_t workspace_bytes, void *stream) {
+    set_linear8_workspace(workspace, workspace ? workspace_bytes : 0);
+    const int rc = mbnb_linear_int8(X, dtype, M, K, W, W_scales, N, bias, out, stream);
+    set_linear8_workspace(nullptr, 0);
+    return rc;
 }
 
 }  // extern "C"

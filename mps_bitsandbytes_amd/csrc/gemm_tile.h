@@ -40,6 +40,17 @@ template <> struct Mfma<bf16_t> {
     }
 };
 
+// 16 x 16 x 32 MFMA (skinny kernels): A lane l = row l & 15, k chunk l >> 4; D[a][b]: a = 4 * (l >> 4) + r, b = l & 15
+template <typename T> struct Mfma16;
+template <> struct Mfma16<f16_t> {
+    using frag = f16x8;
+    static __device__ __forceinline__ f32x4 run(frag a, frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+template <> struct Mfma16<bf16_t> {
+    using frag = bf16x8;
+    static __device__ __forceinline__ f32x4 run(frag a, frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+
 // ------------------------------------------------------------------ B-tile producers
 // A producer owns, per thread, the raw bytes of 32 consecutive k of one weight row for the
 // current k-tile (`fetch`), and later turns them into 64 bytes of 16-bit values written to

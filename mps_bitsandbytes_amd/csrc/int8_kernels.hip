@@ -428,6 +428,97 @@ __global__ __launch_bounds__(256) void k_linear_i8_generic(const T *__restrict__
     if (lane == 0) out[m * N + n] = from_f32<T>(acc + (bias ? to_f32(bias[n]) : 0.0f));
 }
 
+// ------------------------------------------------------------------ skinny W8A16 (1 <= M <= 64)
+// The weight-streaming kernel of matmul4_kernels.hip (k_skinny4) for int8 weights: a workgroup = 16 waves x one group of
+// 16 weight rows; wave w contracts the 128-k blocks w, w+16, ... with all M activation rows on v_mfma_f32_16x16x32.
+// Lane quarter q owns k in [32q, 32q+32) of a block: 32 weight bytes = two 16-byte loads; bytes 8g .. 8g+7 are the A
+// fragment of MFMA g after sign-extend -> * (scale/127) -> RNE 16 bit (dequantize_rowwise bits); the activation
+// fragment of MFMA g is the 16 bytes at k = 32q + 8g.  Partial tiles are added in wave order through LDS.
+template <typename T, int MT>
+__global__ __launch_bounds__(1024) void k_skinny8(const T *__restrict__ X, const int8_t *__restrict__ W, const float *__restrict__ scales,
+                                                 const T *__restrict__ bias, T *__restrict__ out, int64_t M, int64_t N, int64_t K) {
+    constexpr int WV = 16;
+    extern __shared__ __attribute__((aligned(16))) char red_raw[];   // [WV][MT][256] f32
+    float *red = reinterpret_cast<float *>(red_raw);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r16 = lane & 15, q = lane >> 4;
+    const int64_t n0 = (int64_t)blockIdx.x * 16;
+    int64_t nrow = n0 + r16;
+    nrow = nrow < N ? nrow : N - 1;
+    const int8_t *wrow = W + nrow * K;
+    const float sc = scales[nrow] / 127.0f;
+    const T *xrow[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+        int64_t m = 16 * mt + r16;
+        m = m < M ? m : M - 1;
+        xrow[mt] = X + m * K;
+    }
+    f32x4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) acc[mt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    const int64_t nb128 = K >> 7;
+    u32x4 w[2], w_n[2];
+    auto request_w = [&](int64_t b) {
+        const int64_t k_lane = (b << 7) + 32 * q;
+        w_n[0] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(wrow + k_lane));
+        w_n[1] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(wrow + k_lane + 16));
+    };
+    if (wave < nb128) request_w(wave);
+    for (int64_t b = wave; b < nb128; b += WV) {
+        const int64_t k_lane = (b << 7) + 32 * q;
+        typename Mfma16<T>::frag xf[MT][4];
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+                xf[mt][g] = *reinterpret_cast<const typename Mfma16<T>::frag *>(xrow[mt] + k_lane + 8 * g);
+        __builtin_amdgcn_sched_barrier(0);
+        w[0] = w_n[0];
+        w[1] = w_n[1];
+        if (b + WV < nb128) request_w(b + WV);
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            u32x4 fr;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t wd = w[g >> 1][2 * (g & 1) + (j >> 1)];
+                const float q0 = (float)(int)(int8_t)(wd >> (16 * (j & 1)));
+                const float q1 = (float)(int)(int8_t)(wd >> (16 * (j & 1) + 8));
+                fr[j] = pack2<T>(q0 * sc, q1 * sc);
+            }
+            const auto af = __builtin_bit_cast(typename Mfma16<T>::frag, fr);
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) acc[mt] = Mfma16<T>::run(af, xf[mt][g], acc[mt]);
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) *reinterpret_cast<f32x4 *>(red + ((wave * MT + mt) * 256 + lane * 4)) = acc[mt];
+    __syncthreads();
+    for (int t = threadIdx.x; t < MT * 256; t += 1024) {
+        const int mt = t >> 8, e = t & 255;
+        float s = 0.0f;
+#pragma unroll
+        for (int wv = 0; wv < WV; wv++) s += red[(wv * MT + mt) * 256 + e];
+        const int ln = e >> 2, r = e & 3;
+        const int64_t n = n0 + 4 * (ln >> 4) + r;
+        const int64_t m = 16 * mt + (ln & 15);
+        if (n < N && m < M) {
+            const float v = s + (bias ? to_f32(bias[n]) : 0.0f);
+            out[m * N + n] = from_f32<T>(v);
+        }
+    }
+}
+
+// split-K workspace of mbnb_linear_int8_ws for the duration of one call (see matmul4_kernels.hip)
+static thread_local float *tls_ws8 = nullptr;
+static thread_local int64_t tls_ws8_bytes = 0;
+void set_linear8_workspace(void *ws, int64_t bytes) {
+    tls_ws8 = static_cast<float *>(ws);
+    tls_ws8_bytes = bytes;
+}
+int64_t matmul4_splitk_slices(int64_t M, int64_t N, int64_t K);
+
 template <typename T>
 static int launch_linear_int8(const void *X, int64_t M, int64_t K, const int8_t *W, const float *scales, int64_t N,
                               const void *bias, void *out, hipStream_t st) {
@@ -435,6 +526,20 @@ static int launch_linear_int8(const void *X, int64_t M, int64_t K, const int8_t 
     const T *b = static_cast<const T *>(bias);
     T *o = static_cast<T *>(out);
     if constexpr (sizeof(T) == 2) {
+        if (M >= 1 && M <= 64 && (K % 128 == 0) && (((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(W)) & 15) == 0)) {
+            const unsigned grid = (unsigned)((N + 15) / 16);
+#define MBNB_SKINNY8(MT)                                                                                            \
+    do {                                                                                                            \
+        constexpr int lds = 16 * MT * 1024;                                                                         \
+        hipLaunchKernelGGL((k_skinny8<T, MT>), dim3(grid), dim3(1024), lds, st, x, W, scales, b, o, M, N, K);       \
+    } while (0)
+            if (M <= 16) MBNB_SKINNY8(1);
+            else if (M <= 32) MBNB_SKINNY8(2);
+            else MBNB_SKINNY8(4);
+#undef MBNB_SKINNY8
+            set_kernel_name("w8a16_skinny");
+            return check_launch("linear_int8(skinny)");
+        }
         const bool fast = (K % 16 == 0) && (((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(W)) & 15) == 0) && M > 4;
         if (fast && (K % 64 == 0) && ((M + 255) / 256) * ((N + 255) / 256) >= 96) {
             // large problems: the 256 x 256 one-workgroup-per-CU kernel with the int8 -> 16-bit decode in the
@@ -481,6 +586,18 @@ static int launch_linear_int8(const void *X, int64_t M, int64_t K, const int8_t 
                 return (int)e;
             }
             const int64_t tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+            const int64_t slices = matmul4_splitk_slices(M, N, K);   // same policy as the 4-bit path
+            if (slices > 1 && tls_ws8 != nullptr && ((reinterpret_cast<uintptr_t>(tls_ws8) & 15) == 0) &&
+                tls_ws8_bytes >= slices * tiles * 65536) {
+                const int64_t kps = (((K / 64) + slices - 1) / slices) * 64;
+                hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)slices), dim3(256), lds, st, x, wp, b, o, M, N, K, tls_ws8, kps);
+                int rc = check_launch("linear_int8(mfma128 split-K)");
+                if (rc) return rc;
+                hipLaunchKernelGGL((k_splitk_reduce<T, T>), dim3((unsigned)(tiles * 16)), dim3(256), 0, st, tls_ws8, (int)slices, b, o,
+                                   M, N, (M + BM - 1) / BM, tiles);
+                set_kernel_name("w8a16_mfma128_splitk");
+                return check_launch("linear_int8(split-K reduce)");
+            }
             hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, st, x, wp, b, o, M, N, K, static_cast<float *>(nullptr), (int64_t)0);
             set_kernel_name("w8a16_mfma128");
             return check_launch("linear_int8(mfma)");

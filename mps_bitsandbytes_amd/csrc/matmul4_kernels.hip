@@ -290,16 +290,6 @@ __global__ __launch_bounds__(256) void k_gemv4(const T *__restrict__ X, const ui
 // accumulators of a workgroup are added in wave order through LDS (deterministic), then bias and one rounding.
 // Needs K % 128 == 0, blocksize >= 32, 16-bit types.
 // =====================================================================================
-template <typename T> struct Mfma16;
-template <> struct Mfma16<f16_t> {
-    using frag = f16x8;
-    static __device__ __forceinline__ f32x4 run(frag a, frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
-};
-template <> struct Mfma16<bf16_t> {
-    using frag = bf16x8;
-    static __device__ __forceinline__ f32x4 run(frag a, frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
-};
-
 template <typename T, typename OutT, int QT, bool NESTED, int MT, int NR>
 __global__ __launch_bounds__(1024) void k_skinny4(const T *__restrict__ X, const uint8_t *__restrict__ packed, AbsmaxView am,
                                                  const T *__restrict__ bias, OutT *__restrict__ out, int64_t M, int64_t N,

@@ -495,3 +495,33 @@ def test_quantize_model_replaces_linears_and_matches_layerwise_oracle():
     q8 = bnb.quantize_model(copy.deepcopy(ref), load_in_8bit=True)
     assert isinstance(q8.up, bnb.Linear8bit) and q8(x).shape == (5, 32)
     assert bnb.get_memory_footprint(qm)["quantized_params"] > 0
+
+
+@pytest.mark.parametrize("M,N,K,dt,bias", [(1, 4096, 4096, torch.bfloat16, False), (7, 1000, 384, torch.float16, True),
+                                            (16, 11008, 4096, torch.bfloat16, True), (33, 300, 256, torch.float16, False),
+                                            (64, 4096, 1024, torch.bfloat16, True)])
+def test_linear_int8_skinny_path(M, N, K, dt, bias):
+    """Linear8bit.forward for 1 <= M <= 64: the int8 weight-streaming MFMA kernel (k_skinny8) vs the oracle."""
+    W = synthetic.normal((N, K), dt, seed=61, std=0.05)
+    q, s = oracle.quantize_rowwise(W)
+    x = synthetic.normal((M, K), dt, seed=62)
+    b = synthetic.normal((N,), dt, seed=63) if bias else None
+    y = bnb.linear_int8(x.to(DEV), q.to(DEV), s.to(DEV), None if b is None else b.to(DEV))
+    assert _native.last_kernel() == "w8a16_skinny"
+    ref = oracle.linear_int8(x, q, s, b)
+    assert rel_fro(y, ref) <= TOL[dt]
+
+
+@pytest.mark.parametrize("M,N,K,dt,bias", [(128, 4096, 4096, torch.bfloat16, True), (300, 1000, 1024, torch.float16, False),
+                                            (1024, 2048, 2048, torch.bfloat16, True)])
+def test_linear_int8_splitk_path(M, N, K, dt, bias):
+    """Linear8bit.forward for mid-sized M: 128 x 128 tiles, K split over a workspace (mbnb_linear_int8_ws)."""
+    W = synthetic.normal((N, K), dt, seed=71, std=0.05)
+    q, s = oracle.quantize_rowwise(W)
+    x = synthetic.normal((M, K), dt, seed=72)
+    b = synthetic.normal((N,), dt, seed=73) if bias else None
+    y = bnb.linear_int8(x.to(DEV), q.to(DEV), s.to(DEV), None if b is None else b.to(DEV))
+    assert _native.last_kernel() == "w8a16_mfma128_splitk"
+    rows = torch.arange(0, M, max(1, M // 64))[:64]
+    ref = oracle.linear_int8(x[rows], q, s, b)
+    assert rel_fro(y.cpu()[rows], ref) <= TOL[dt]
