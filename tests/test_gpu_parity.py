@@ -525,3 +525,45 @@ def test_linear_int8_splitk_path(M, N, K, dt, bias):
     rows = torch.arange(0, M, max(1, M // 64))[:64]
     ref = oracle.linear_int8(x[rows], q, s, b)
     assert rel_fro(y.cpu()[rows], ref) <= TOL[dt]
+
+
+def test_matmul_4bit_randomized_dispatch_sweep():
+    """120 pseudo-random (M, N, K, blocksize, dtype, table, nested absmax, bias, compute dtype) cases against the oracle:
+    every dispatch branch (gemv, skinny, 128^2, split-K, generic; 256^2 needs >= 96 tiles and has its own tests) is
+    hit with shapes nobody picked by hand."""
+    rng = np.random.default_rng(20261004)
+    seen = {}
+    for case in range(120):
+        M = int(rng.choice([1, 2, 3, 5, 8, 16, 17, 31, 33, 64, 65, 100, 129, 200, 257, 300, 513]))
+        N = int(rng.choice([1, 7, 16, 31, 48, 64, 100, 128, 200, 256, 384, 513, 777, 1024]))
+        K = int(rng.choice([8, 24, 32, 64, 72, 96, 128, 192, 256, 320, 384, 512, 640, 1024, 2048]))
+        bs = int(rng.choice([16, 32, 64, 128, 256]))
+        dt = [torch.float16, torch.bfloat16, torch.float32][int(rng.integers(0, 3))] if rng.random() < 0.2 else [torch.float16, torch.bfloat16][int(rng.integers(0, 2))]
+        qt = "nf4" if rng.random() < 0.7 else "fp4"
+        cs = bool(rng.random() < 0.35)
+        bias = bool(rng.random() < 0.5)
+        cd = None if rng.random() < 0.7 else [torch.float16, torch.bfloat16, torch.float32][int(rng.integers(0, 3))]
+        kern = _oracle_vs_gpu_matmul(M, N, K, dt, qt=qt, bs=bs, cs=cs, bias=bias, cd=cd, seed=1000 + case)
+        seen[kern] = seen.get(kern, 0) + 1
+    assert {"gemv", "skinny_mfma16", "mfma128", "mfma128_splitk", "generic"} <= set(seen), seen
+
+
+def test_linear_int8_randomized_dispatch_sweep():
+    """60 pseudo-random Linear8bit.forward shapes against the oracle (skinny, 128^2, split-K and generic paths)."""
+    rng = np.random.default_rng(20261005)
+    seen = {}
+    for case in range(60):
+        M = int(rng.choice([1, 2, 5, 16, 17, 33, 64, 65, 100, 129, 257, 300]))
+        N = int(rng.choice([1, 7, 16, 48, 100, 128, 200, 384, 513, 1024]))
+        K = int(rng.choice([8, 16, 24, 64, 72, 128, 192, 256, 384, 512, 1024, 2048]))
+        dt = [torch.float16, torch.bfloat16][int(rng.integers(0, 2))]
+        W = synthetic.normal((N, K), dt, seed=2000 + case, std=0.05)
+        q, s = oracle.quantize_rowwise(W)
+        x = synthetic.normal((M, K), dt, seed=3000 + case)
+        b = synthetic.normal((N,), dt, seed=4000 + case) if rng.random() < 0.5 else None
+        y = bnb.linear_int8(x.to(DEV), q.to(DEV), s.to(DEV), None if b is None else b.to(DEV))
+        kern = _native.last_kernel()
+        seen[kern] = seen.get(kern, 0) + 1
+        err = rel_fro(y, oracle.linear_int8(x, q, s, b))
+        assert err <= TOL[dt], f"case {case}: M={M} N={N} K={K} {dt} ({kern}): {err:.3e}"
+    assert {"w8a16_skinny", "w8a16_mfma128", "w8a16_generic"} <= set(seen), seen
