@@ -312,6 +312,24 @@ def main():
         elapsed = float(t.item())
     kernel_name = _native.last_kernel()
 
+    # N > 1 with the gather: a second timed region WITHOUT it (same bracket: barrier + synchronize, max over ranks), so
+    # one run carries both the headline (GEMM + all-gather) and the communication-free scaling of the sharded GEMM
+    gemm_only = None
+    if gathered is not None:
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            bnb.matmul_4bit(X, packed, state)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        e2 = time.perf_counter() - t1
+        t = torch.tensor([e2], dtype=torch.float64, device="cpu" if rehearse else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        gemm_only = float(t.item())
+
     # kernel-only launch duration (no gather, no host gaps beyond back-to-back launches)
     if wl == "nf4_m1":
         kern_ms = event_time_ms(step, max(1, args.steps // 4)) / 64
@@ -346,6 +364,10 @@ def main():
                          else f"effective TFLOPS, {wl}")
         out["value"] = round(tflops, 2)
         out["unit"] = "TFLOP/s"
+        if gemm_only is not None:
+            out["gemm_only"] = {"value": round(total_flops / (gemm_only / args.steps) / 1e12, 2), "unit": "TFLOP/s",
+                                "ms_per_step": round(gemm_only / args.steps * 1e3, 5),
+                                "note": "same steps without the output all-gather (communication-free scaling of the sharded GEMM)"}
         out["roofline"] = {"bound": "mfma", "achieved": round(kern_tflops, 2), "peak": peak, "unit": "TFLOP/s",
                            "frac": round(kern_tflops / peak, 4), "traffic": None,
                            "kernel_us": round(kern_ms * 1e3, 2)}
