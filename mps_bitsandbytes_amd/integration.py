@@ -42,16 +42,14 @@ class BitsAndBytesConfig:
         if self.llm_int8_skip_modules is None:
             self.llm_int8_skip_modules = []
 
+    _EXPORTED = ('load_in_8bit', 'load_in_4bit', 'llm_int8_threshold', 'llm_int8_skip_modules',
+                 'bnb_4bit_compute_dtype', 'bnb_4bit_quant_type', 'bnb_4bit_use_double_quant')
+
     def to_dict(self) -> Dict[str, Any]:
-        return {
-            'load_in_8bit': self.load_in_8bit,
-            'load_in_4bit': self.load_in_4bit,
-            'llm_int8_threshold': self.llm_int8_threshold,
-            'llm_int8_skip_modules': self.llm_int8_skip_modules,
-            'bnb_4bit_compute_dtype': str(self.bnb_4bit_compute_dtype),
-            'bnb_4bit_quant_type': self.bnb_4bit_quant_type,
-            'bnb_4bit_use_double_quant': self.bnb_4bit_use_double_quant,
-        }
+        """The serialisable subset (same keys as the reference; the compute dtype as its string name)."""
+        out = {name: getattr(self, name) for name in self._EXPORTED}
+        out['bnb_4bit_compute_dtype'] = str(out['bnb_4bit_compute_dtype'])
+        return out
 
     @classmethod
     def from_dict(cls, config_dict: Dict[str, Any]) -> 'BitsAndBytesConfig':
@@ -129,25 +127,12 @@ def get_memory_footprint(model: nn.Module) -> Dict[str, Any]:
     """Parameter/buffer byte counts vs an all-fp16 model (reference: integration.py:254-287).  Unlike the
     reference, whose name filter ('weight_packed'/'weight_int8') misses Linear4bit's `weight` buffer,
     quantized buffers are recognised by owner module type."""
-    total_bytes = total_params = quantized_params = 0
-    for _, p in model.named_parameters():
-        total_params += p.numel()
-        total_bytes += p.numel() * p.element_size()
-    for _, b in model.named_buffers():
-        total_params += b.numel()
-        total_bytes += b.numel() * b.element_size()
-    for m in model.modules():
-        if isinstance(m, Linear4bit):
-            quantized_params += m.weight.numel()
-        elif isinstance(m, Linear8bit):
-            quantized_params += m.weight_int8.numel()
-    fp16_size = total_params * 2 / 1e9
-    actual_size = total_bytes / 1e9
-    return {
-        'total_params': total_params,
-        'quantized_params': quantized_params,
-        'fp16_size_gb': fp16_size,
-        'actual_size_gb': actual_size,
-        'savings_gb': fp16_size - actual_size,
-        'savings_pct': (1 - actual_size / fp16_size) * 100 if fp16_size > 0 else 0,
-    }
+    tensors = [t for _, t in model.named_parameters()] + [t for _, t in model.named_buffers()]
+    n_values = sum(t.numel() for t in tensors)
+    n_bytes = sum(t.numel() * t.element_size() for t in tensors)
+    n_quantized = sum(m.weight.numel() if isinstance(m, Linear4bit) else m.weight_int8.numel()
+                      for m in model.modules() if isinstance(m, (Linear4bit, Linear8bit)))
+    as_fp16_gb, actual_gb = n_values * 2 / 1e9, n_bytes / 1e9
+    return {'total_params': n_values, 'quantized_params': n_quantized, 'fp16_size_gb': as_fp16_gb,
+            'actual_size_gb': actual_gb, 'savings_gb': as_fp16_gb - actual_gb,
+            'savings_pct': (1 - actual_gb / as_fp16_gb) * 100 if as_fp16_gb > 0 else 0}

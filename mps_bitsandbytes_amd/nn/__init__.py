@@ -1,8 +1,14 @@
-"""Quantized layers (reference: mps_bitsandbytes/nn/__init__.py)."""
+"""
+Quantized layers of the MI355X backend.
+
+Each layer keeps the reference's public surface (mps_bitsandbytes/nn/*.py) and runs its forward through one entry
+point of the HIP library: Linear4bit -> matmul_4bit, Linear8bit -> linear_int8, OutlierAwareLinear -> outlier_linear,
+Embedding4bit / Embedding8bit -> embedding_4bit / embedding_8bit.  `_base.py` holds what they share.
+"""
+from .embedding import Embedding4bit, Embedding8bit, EmbeddingFP4, EmbeddingNF4
 from .linear4bit import Linear4bit, Params4bit
 from .linear8bit import Linear8bit
-from .embedding import Embedding4bit, Embedding8bit, EmbeddingNF4, EmbeddingFP4
 from .outlier_aware import OutlierAwareLinear
 
-__all__ = ['Linear4bit', 'Linear8bit', 'Params4bit', 'Embedding4bit', 'Embedding8bit', 'EmbeddingNF4', 'EmbeddingFP4',
-           'OutlierAwareLinear']
+__all__ = sorted(['Linear4bit', 'Params4bit', 'Linear8bit', 'OutlierAwareLinear',
+                  'Embedding4bit', 'Embedding8bit', 'EmbeddingNF4', 'EmbeddingFP4'])

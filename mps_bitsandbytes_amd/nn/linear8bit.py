@@ -1,73 +1,60 @@
 """
-Linear8bit — rowwise-INT8 quantized linear layer on MI355X.
+Linear8bit — row-wise INT8 linear layer on MI355X.
 
-Same constructor, buffers (`weight_int8` [N,K] int8, `weight_scales` [N] f32), `from_linear`,
-cache API and `device` property as the reference (mps_bitsandbytes/nn/linear8bit.py:15-166).
-`forward` does not materialise the dequantized weight: the int8 rows are decoded inside the
-MFMA GEMM's B-tile producer (functional.linear_int8), giving the same result as the reference's
-dequantize_rowwise -> F.linear.
+Public surface of the reference module (mps_bitsandbytes/nn/linear8bit.py:15-166): buffers `weight_int8` [N, K] int8
+and `weight_scales` [N] f32 (the row absmax), `from_linear`, the dequantized-weight cache API and `device`.
+The forward never materialises the dequantized weight: `functional.linear_int8` decodes the int8 rows inside the GEMM
+(skinny MFMA, split-K or the 256 x 256 LDS-DMA kernel), with the reference's dequantize_rowwise -> F.linear result.
 """
 from typing import Optional
 
 import torch
 from torch import nn, Tensor
 
-from ..functional import quantize_rowwise, dequantize_rowwise, linear_int8
+from .. import functional as F
+from ._base import QuantizedModule, compute_dtype_for, source_device
 
 
-class Linear8bit(nn.Module):
+class Linear8bit(QuantizedModule):
+    _anchor = 'weight_int8'
+
     def __init__(self, in_features: int, out_features: int, bias: bool = True, device=None,
                  use_cache: bool = True, compute_dtype: torch.dtype = torch.float16):
         super().__init__()
-        self.in_features = in_features
-        self.out_features = out_features
+        self._init_linear(in_features, out_features, compute_dtype)
         self.use_cache = use_cache
-        self.compute_dtype = compute_dtype
         self.register_buffer('weight_int8', torch.zeros(out_features, in_features, dtype=torch.int8, device=device))
         self.register_buffer('weight_scales', torch.ones(out_features, dtype=torch.float32, device=device))
-        if bias:
-            self.bias = nn.Parameter(torch.zeros(out_features, dtype=compute_dtype, device=device))
-        else:
-            self.register_parameter('bias', None)
+        self._init_bias(bias, device)
         self._weight_cache: Optional[Tensor] = None
 
+    def forward(self, x: Tensor) -> Tensor:
+        return F.linear_int8(x, self.weight_int8, self.weight_scales, self.bias, dtype=self.compute_dtype)
+
+    # dequantized view for LoRA merges / debugging (reference :70-89); forward() does not use it
     def _get_weight(self) -> Tensor:
-        """Dequantized weight in compute_dtype, cached when use_cache (reference :70-85).  Kept for
-        API compatibility (LoRA merges, debugging); forward() does not need it."""
-        if self.use_cache and self._weight_cache is not None:
-            return self._weight_cache
-        weight = dequantize_rowwise(self.weight_int8, self.weight_scales, dtype=self.compute_dtype)
-        if self.use_cache:
-            self._weight_cache = weight
-        return weight
+        cached = self._weight_cache if self.use_cache else None
+        if cached is None:
+            cached = F.dequantize_rowwise(self.weight_int8, self.weight_scales, dtype=self.compute_dtype)
+            if self.use_cache:
+                self._weight_cache = cached
+        return cached
 
     def clear_cache(self):
         self._weight_cache = None
 
-    def forward(self, x: Tensor) -> Tensor:
-        """x [..., in_features] -> [..., out_features] (reference :91-102), fused W8A16 kernel."""
-        return linear_int8(x, self.weight_int8, self.weight_scales, self.bias, dtype=self.compute_dtype)
-
     @classmethod
     def from_linear(cls, linear: nn.Linear, device=None, use_cache: bool = True,
                     compute_dtype: Optional[torch.dtype] = None) -> 'Linear8bit':
-        """Convert an nn.Linear (reference :104-151); weights are quantized on `device` by the HIP kernel."""
-        if device is None:
-            device = linear.weight.device
-        if compute_dtype is None:
-            compute_dtype = torch.bfloat16 if linear.weight.dtype == torch.bfloat16 else torch.float16
+        """Quantize an nn.Linear on `device` with the HIP kernel (reference :104-151)."""
+        device = source_device(linear.weight, device)
         layer = cls(linear.in_features, linear.out_features, bias=linear.bias is not None, device=device,
-                    use_cache=use_cache, compute_dtype=compute_dtype)
-        weight_int8, weight_scales = quantize_rowwise(linear.weight.data.to(device))
-        layer.weight_int8.copy_(weight_int8)
-        layer.weight_scales.copy_(weight_scales.to(torch.float32))
-        if linear.bias is not None:
-            layer.bias.data.copy_(linear.bias.data.to(compute_dtype).to(device))
+                    use_cache=use_cache, compute_dtype=compute_dtype_for(linear.weight.dtype, compute_dtype))
+        q, absmax = F.quantize_rowwise(linear.weight.data.to(device))
+        layer.weight_int8.copy_(q)
+        layer.weight_scales.copy_(absmax.float())
+        layer._copy_bias_from(linear, device)
         return layer
 
-    @property
-    def device(self) -> torch.device:
-        return self.weight_int8.device
-
     def extra_repr(self) -> str:
-        return f'in_features={self.in_features}, out_features={self.out_features}, bias={self.bias is not None}'
+        return self._repr_core()
