@@ -45,19 +45,31 @@ __device__ __forceinline__ void load8(const T *A, int64_t rows, int64_t cols, in
     }
 }
 
+// argmin_i fl(|xn - code[i]|) with the first minimum (functional.py:242-243), without the 16-way search.
+// For a sorted table the reference's own rounded comparison between neighbours flips exactly once along the f32
+// number line, at a threshold t_i (the largest f32 that still prefers code[i]); the argmin is #{i : xn > t_i}.
+// The thresholds are found and checked against the brute-force argmin (2.8 M values: every f32 within 4096 ulps of
+// each threshold and code, plus random ones) by tools/gen_code_thresholds.py.  FP4's table is symmetric: search
+// |xn| among the non-negative codes, then index 8 + j for negative inputs -- except j = 0: -0.0 (index 8) ties with
+// +0.0 (index 0) and the first minimum wins, so index 8 is never produced.  NaN compares false everywhere -> 0, as
+// torch.argmin over all-NaN distances.
 template <int QT> __device__ __forceinline__ uint32_t nearest_code(float xn) {
-    // argmin_i |xn - code[i]| with first-minimum tie-break (functional.py:242-243; strict `<`)
-    uint32_t best = 0;
-    float bd = fabsf(xn - code_value<QT>(0));
+    if constexpr (QT == MBNB_NF4) {
+        constexpr uint32_t T[15] = {0xbf591cd9u, 0xbf1c5271u, 0xbeeb8480u, 0xbeadea77u, 0xbe703cedu, 0xbe0d38bcu, 0xbd3a7871u,
+                                    0x3d22faffu, 0x3df64862u, 0x3e5067e0u, 0x3e9582d4u, 0x3ec753f9u, 0x3f006d03u, 0x3f248dafu,
+                                    0x3f5c89d9u};
+        uint32_t idx = 0;
 #pragma unroll
-    for (int i = 1; i < 16; i++) {
-        float d = fabsf(xn - code_value<QT>(i));
-        if (d < bd) {
-            bd = d;
-            best = i;
-        }
+        for (int i = 0; i < 15; i++) idx += (xn > __builtin_bit_cast(float, T[i])) ? 1u : 0u;
+        return idx;
+    } else {
+        constexpr float U[7] = {0.03125f, 0.09375f, 0.1875f, 0.3125f, 0.4375f, 0.625f, 0.875f};
+        const float a = fabsf(xn);
+        uint32_t j = 0;
+#pragma unroll
+        for (int i = 0; i < 7; i++) j += (a > U[i]) ? 1u : 0u;
+        return (xn < 0.0f && j > 0) ? 8u + j : j;
     }
-    return best;
 }
 
 template <typename T, int QT>
