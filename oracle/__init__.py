@@ -44,7 +44,8 @@ def lib():
         for name in ("orc_quantize_4bit", "orc_dequantize_4bit", "orc_quantize_blockwise",
                      "orc_dequantize_blockwise", "orc_quantize_rowwise", "orc_dequantize_rowwise",
                      "orc_double_quant", "orc_matmul_4bit", "orc_matmul_int8", "orc_linear_int8",
-                     "orc_embedding_4bit", "orc_embedding_8bit", "orc_outlier_linear"):
+                     "orc_embedding_4bit", "orc_embedding_8bit", "orc_outlier_linear",
+                     "orc_quantize_fp8_e4m3", "orc_dequantize_fp8_e4m3", "orc_linear_fp8"):
             getattr(_lib, name).restype = ctypes.c_int
     return _lib
 
@@ -282,4 +283,38 @@ def outlier_linear(x: torch.Tensor, weight_int8: torch.Tensor, weight_scales: to
                                   _p(weight_scales.float().contiguous()), _i64(N),
                                   _p(oi) if oi.numel() else None, _i64(oi.numel()),
                                   _p(ow) if oi.numel() else None, _p(b), _p(out)), "outlier_linear")
+    return out.reshape(*lead, N)
+
+
+def quantize_fp8_e4m3(t: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """functional.py:643-663 / :1086-1163 (the reference's own E4M3 encoder, restated literally)."""
+    t = t.contiguous()
+    rows, cols = t.shape
+    out = torch.empty(rows, cols, dtype=torch.uint8)
+    scales = torch.empty(rows, dtype=torch.float32)
+    _chk(lib().orc_quantize_fp8_e4m3(_p(t), _DT[t.dtype], _i64(rows), _i64(cols), _p(out), _p(scales)), "quantize_fp8_e4m3")
+    return out, scales
+
+
+def dequantize_fp8_e4m3(q: torch.Tensor, scales: torch.Tensor, dtype: torch.dtype = torch.float16) -> torch.Tensor:
+    """functional.py:666-673 / :1166-1215."""
+    q = q.contiguous()
+    rows, cols = q.shape
+    out = torch.empty(rows, cols, dtype=dtype)
+    _chk(lib().orc_dequantize_fp8_e4m3(_p(q), _p(scales.float().contiguous()), _i64(rows), _i64(cols), _DT[dtype], _p(out)),
+         "dequantize_fp8_e4m3")
+    return out
+
+
+def linear_fp8(x: torch.Tensor, weight_fp8: torch.Tensor, weight_scales: torch.Tensor,
+               bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """matmul_fp8_e4m3 / LinearFP8.forward (functional.py:796-807); x and bias in the compute dtype."""
+    lead = x.shape[:-1]
+    x2 = x.reshape(-1, x.shape[-1]).contiguous()
+    M, K = x2.shape
+    N = weight_fp8.shape[0]
+    out = torch.empty(M, N, dtype=x.dtype)
+    b = None if bias is None else bias.to(x.dtype).contiguous()
+    _chk(lib().orc_linear_fp8(_p(x2), _DT[x.dtype], _i64(M), _i64(K), _p(weight_fp8.contiguous()),
+                              _p(weight_scales.float().contiguous()), _i64(N), _p(b), _p(out)), "linear_fp8")
     return out.reshape(*lead, N)

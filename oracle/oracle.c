@@ -558,6 +558,118 @@ int orc_outlier_linear(const void *X, int dtype, int64_t M, int64_t K, const int
     return 0;
 }
 
+/* ---------------------------------------------------------------------------
+ * FP8 E4M3 — functional.py:643-673 (entry points), :1086-1163 (encode), :1166-1215 (decode), :796-807 (matmul).
+ *
+ * The reference's encoder is NOT the OCP conversion; it is restated literally:
+ *   scales = clamp(max|row| / 448, 1e-12)          normalized = clamp(x / scale, -448, 448)
+ *   exp = floor(log2(|v|))  (torch.log2 in f32)     biased = exp + 7
+ *   mant = trunc(clamp((|v| / 2^exp - 1) * 8 + 0.5, 0, 7))     (no carry into the exponent)
+ *   biased <= 0 -> sign only (subnormals flushed)   biased >= 15 -> sign | 0x77 (so every |v| >= 256 becomes 240)
+ *   zero -> sign, NaN -> 0x7F
+ * torch.log2 is correctly rounded around the integers that matter here, which makes floor(log2(v)) jump to k already
+ * a few ulps BELOW 2^k (log2(2^k - n ulp) rounds to k): n_k = 2 for k in [-7,-4], 1 for -3,-2, 0 for -1..2, 1 for 3,4,
+ * 2 for 5..8, 5 for 9 (measured on torch 2.10 CPU by tests/golden/make_golden_fp8.py, which also pins this function).
+ * fp8_exponent() applies that rule on the bits so the restatement does not depend on a libm.
+ * ------------------------------------------------------------------------- */
+static inline int fp8_round_up_ulps(int k) {   /* how many f32 values below 2^k already report exponent k */
+    if (k >= 9) return 5;
+    if (k >= 5) return 2;
+    if (k >= 3) return 1;
+    if (k >= -1) return 0;
+    if (k >= -3) return 1;
+    if (k >= -7) return 2;
+    if (k >= -15) return 5;
+    return 11;
+}
+static inline int fp8_exponent(float a) {      /* floor(torch.log2(a)) for finite a > 0 */
+    uint32_t u = f32_bits(a);
+    int e = (int)((u >> 23) & 0xFF) - 127;
+    uint32_t mant = u & 0x7FFFFFu;
+    if (((u >> 23) & 0xFF) == 0) {             /* f32 subnormal: far below the FP8 range, exponent only needs to be <= -8 */
+        return -127;
+    }
+    if ((0x7FFFFFu - mant) < (uint32_t)fp8_round_up_ulps(e + 1)) e += 1;
+    return e;
+}
+static inline uint8_t float_to_fp8_e4m3_ref(float v) {
+    if (v != v) return 0x7F;
+    uint8_t sign = v < 0.0f ? 0x80 : 0x00;
+    float a = fabsf(v);
+    if (a > 448.0f) a = 448.0f;
+    if (a == 0.0f) return sign;
+    int e = fp8_exponent(a);
+    int biased = e + 7;
+    if (biased >= 15) return (uint8_t)(sign | 0x77);
+    if (biased <= 0) return sign;
+    float m = a / ldexpf(1.0f, e) - 1.0f;
+    float mb = m * 8.0f + 0.5f;
+    if (mb < 0.0f) mb = 0.0f;
+    if (mb > 7.0f) mb = 7.0f;
+    return (uint8_t)(sign | (biased << 3) | (uint8_t)mb);
+}
+static inline float fp8_e4m3_to_float_ref(uint8_t b) {
+    int sign = b >> 7, e = (b >> 3) & 0xF, m = b & 7;
+    float r;
+    if (e == 15 && m == 7) r = NAN;
+    else if (e == 0) r = ((float)m / 8.0f) * 0.015625f;                   /* (mant/8) * 2^-6 */
+    else r = (1.0f + (float)m / 8.0f) * ldexpf(1.0f, e - 7);
+    return sign ? -r : r;
+}
+
+int orc_quantize_fp8_e4m3(const void *A, int dtype, int64_t rows, int64_t cols, uint8_t *out, float *scales) {
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < rows; r++) {
+        float am = 0.0f;
+        for (int64_t c = 0; c < cols; c++) {
+            float v = fabsf(load_elem(A, dtype, r * cols + c));
+            if (v > am || v != v) am = v;                                 /* torch.max propagates NaN */
+        }
+        float s = am / 448.0f;
+        if (s < 1e-12f) s = 1e-12f;
+        scales[r] = s;
+        for (int64_t c = 0; c < cols; c++) {
+            float n = load_elem(A, dtype, r * cols + c) / s;
+            if (n < -448.0f) n = -448.0f;
+            if (n > 448.0f) n = 448.0f;
+            out[r * cols + c] = float_to_fp8_e4m3_ref(n);
+        }
+    }
+    return 0;
+}
+
+int orc_dequantize_fp8_e4m3(const uint8_t *q, const float *scales, int64_t rows, int64_t cols, int out_dtype, void *out) {
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < rows; r++)
+        for (int64_t c = 0; c < cols; c++)
+            store_elem(out, out_dtype, r * cols + c, fp8_e4m3_to_float_ref(q[r * cols + c]) * scales[r]);
+    return 0;
+}
+
+/* matmul_fp8_e4m3 / LinearFP8.forward — functional.py:796-807, nn/linear_fp8.py:74-103:
+ *   W = dequantize_fp8_e4m3(weight[N,K], scales[N], dtype);  F.linear(input.to(dtype), W, bias) */
+int orc_linear_fp8(const void *X, int dtype, int64_t M, int64_t K, const uint8_t *W, const float *W_scales, int64_t N,
+                   const void *bias, void *out) {
+    float *Af = (float *)malloc(sizeof(float) * (size_t)(M * K));
+    float *Wf = (float *)malloc(sizeof(float) * (size_t)(N * K));
+    float *Cf = (float *)malloc(sizeof(float) * (size_t)(M * N));
+    float *bf = bias ? (float *)malloc(sizeof(float) * (size_t)N) : NULL;
+    if (!Af || !Wf || !Cf || (bias && !bf)) { free(Af); free(Wf); free(Cf); free(bf); return -2; }
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < M * K; i++) Af[i] = load_elem(X, dtype, i);
+#pragma omp parallel for schedule(static)
+    for (int64_t n = 0; n < N; n++)
+        for (int64_t k = 0; k < K; k++)
+            Wf[n * K + k] = round_to(dtype, fp8_e4m3_to_float_ref(W[n * K + k]) * W_scales[n]);
+    if (bias)
+        for (int64_t n = 0; n < N; n++) bf[n] = load_elem(bias, dtype, n);
+    sgemm_nt(Af, Wf, bf, Cf, M, N, K);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < M * N; i++) store_elem(out, dtype, i, Cf[i]);
+    free(Af); free(Wf); free(Cf); free(bf);
+    return 0;
+}
+
 int orc_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();
