@@ -199,6 +199,23 @@ int mbnb_outlier_linear(const void *X, int dtype, int64_t M, int64_t K, const in
                         int64_t N, const int64_t *outlier_idx, int64_t n_outliers, const void *outlier_w,
                         const void *bias, void *out, void *workspace, void *stream);
 
+/* ---------------------------------------------------------------------------
+ * FP8 E4M3 in the reference's own format — replaces `_C.quantize_fp8_e4m3` / `_C.dequantize_fp8_e4m3` /
+ * `_C.matmul_fp8_e4m3` (host mm:2157-2260, kernels mm:94-140, :1010-1180) with the numerics of the reference's Python path
+ * (functional.py:643-673, :796-807, :1086-1215), bit-exact for quantize / dequantize:
+ *   scales[r] = clamp(max|row| / 448, 1e-12);  byte = encode(clamp(x / scale, +-448))  with the reference's encoder
+ *   (exponent = floor(log2 |v|) as torch evaluates it, mantissa = trunc((|v|/2^e - 1) * 8 + 0.5) without carry,
+ *   subnormals flushed to signed zero, |v| >= 256 -> 0x77, NaN -> 0x7F) — not the OCP conversion.
+ *   linear_fp8: out[M,N] = X[M,K] . round_dtype(decode(W[N,K]) * scales[n])^T + bias   (LinearFP8.forward,
+ *   nn/linear_fp8.py:74-103); same kernels and optional split-K workspace as mbnb_linear_int8_ws.
+ * ------------------------------------------------------------------------- */
+int mbnb_quantize_fp8_e4m3(const void *A, int dtype, int64_t rows, int64_t cols, uint8_t *out, float *scales,
+                           void *stream);
+int mbnb_dequantize_fp8_e4m3(const uint8_t *q, const float *scales, int64_t rows, int64_t cols, int out_dtype,
+                             void *out, void *stream);
+int mbnb_linear_fp8(const void *X, int dtype, int64_t M, int64_t K, const uint8_t *W, const float *W_scales,
+                    int64_t N, const void *bias, void *out, void *workspace, int64_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,8 +19,9 @@ from .functional import (
     quantize_blockwise, dequantize_blockwise,
     quantize_rowwise, dequantize_rowwise, matmul_int8, linear_int8,
     double_quant, dequant_absmax, embedding_4bit, embedding_8bit, outlier_linear,
+    quantize_fp8_e4m3, dequantize_fp8_e4m3, matmul_fp8_e4m3,
 )
-from .nn import (Linear4bit, Linear8bit, Params4bit, Embedding4bit, Embedding8bit, EmbeddingNF4, EmbeddingFP4,
+from .nn import (Linear4bit, Linear8bit, LinearFP8, Params4bit, Embedding4bit, Embedding8bit, EmbeddingNF4, EmbeddingFP4,
                  OutlierAwareLinear)
 from .integration import (
     BitsAndBytesConfig, quantize_model, replace_linear_with_4bit, replace_linear_with_8bit, get_memory_footprint,
@@ -49,5 +50,6 @@ __all__ = [
     'double_quant', 'dequant_absmax',
     'Linear4bit', 'Linear8bit', 'Params4bit', 'Embedding4bit', 'Embedding8bit', 'EmbeddingNF4', 'EmbeddingFP4',
     'OutlierAwareLinear', 'embedding_4bit', 'embedding_8bit', 'outlier_linear',
+    'LinearFP8', 'quantize_fp8_e4m3', 'dequantize_fp8_e4m3', 'matmul_fp8_e4m3',
     'BitsAndBytesConfig', 'quantize_model', 'replace_linear_with_4bit', 'replace_linear_with_8bit', 'get_memory_footprint',
 ]

@@ -58,6 +58,10 @@ _SIGNATURES = {
                                  c_void_p, c_void_p]),
     "mbnb_linear_int8_ws": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
                                     c_void_p, c_void_p, c_int64, c_void_p]),
+    "mbnb_quantize_fp8_e4m3": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+    "mbnb_dequantize_fp8_e4m3": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p]),
+    "mbnb_linear_fp8": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
+                                c_void_p, c_int64, c_void_p]),
     "mbnb_embedding_4bit": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int,
                                     c_int64, c_int, c_void_p, c_void_p]),
     "mbnb_embedding_8bit": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int64, c_int,

@@ -38,6 +38,9 @@ int dequantize_rowwise_dispatch(const int8_t *, const float *, int64_t, int64_t,
 int double_quant_dispatch(const void *, int, int64_t, int64_t, int8_t *, int8_t *, float *, float *, int, int, hipStream_t);
 int matmul_4bit_dispatch(const void *, int64_t, int64_t, const uint8_t *, const AbsmaxView &, int64_t, int64_t, int, int, int, const void *, int, void *, hipStream_t);
 void set_matmul4_workspace(void *, int64_t);
+int quantize_fp8_dispatch(const void *, int, int64_t, int64_t, uint8_t *, float *, hipStream_t);
+int dequantize_fp8_dispatch(const uint8_t *, const float *, int64_t, int64_t, int, void *, hipStream_t);
+int linear_fp8_dispatch(const void *, int, int64_t, int64_t, const uint8_t *, const float *, int64_t, const void *, void *, hipStream_t);
 void set_linear8_workspace(void *, int64_t);
 int64_t matmul4_splitk_slices(int64_t, int64_t, int64_t);
 int matmul_int8_dispatch(const int8_t *, const int8_t *, const float *, const float *, int64_t, int64_t, int64_t, int, void *, void *, hipStream_t);
@@ -260,6 +263,35 @@ int mbnb_linear_int8_ws(const void *X, int dtype, int64_t M, int64_t K, const in
                         const void *bias, void *out, void *workspace, int64_t workspace_bytes, void *stream) {
     set_linear8_workspace(workspace, workspace ? workspace_bytes : 0);
     const int rc = mbnb_linear_int8(X, dtype, M, K, W, W_scales, N, bias, out, stream);
+    set_linear8_workspace(nullptr, 0);
+    return rc;
+}
+
+int mbnb_quantize_fp8_e4m3(const void *A, int dtype, int64_t rows, int64_t cols, uint8_t *out, float *scales, void *stream) {
+    if (!dtype_ok(dtype)) return fail(MBNB_ERR_ARG, "quantize_fp8_e4m3: bad dtype");
+    if (rows < 0 || cols < 0) return fail(MBNB_ERR_ARG, "quantize_fp8_e4m3: negative size");
+    if (rows == 0 || cols == 0) return MBNB_OK;
+    if (!A || !out || !scales) return fail(MBNB_ERR_ARG, "quantize_fp8_e4m3: NULL pointer");
+    return quantize_fp8_dispatch(A, dtype, rows, cols, out, scales, static_cast<hipStream_t>(stream));
+}
+
+int mbnb_dequantize_fp8_e4m3(const uint8_t *q, const float *scales, int64_t rows, int64_t cols, int out_dtype, void *out,
+                             void *stream) {
+    if (!dtype_ok(out_dtype)) return fail(MBNB_ERR_ARG, "dequantize_fp8_e4m3: bad dtype");
+    if (rows < 0 || cols < 0) return fail(MBNB_ERR_ARG, "dequantize_fp8_e4m3: negative size");
+    if (rows == 0 || cols == 0) return MBNB_OK;
+    if (!q || !scales || !out) return fail(MBNB_ERR_ARG, "dequantize_fp8_e4m3: NULL pointer");
+    return dequantize_fp8_dispatch(q, scales, rows, cols, out_dtype, out, static_cast<hipStream_t>(stream));
+}
+
+int mbnb_linear_fp8(const void *X, int dtype, int64_t M, int64_t K, const uint8_t *W, const float *W_scales, int64_t N,
+                    const void *bias, void *out, void *workspace, int64_t workspace_bytes, void *stream) {
+    if (!dtype_ok(dtype)) return fail(MBNB_ERR_ARG, "linear_fp8: bad dtype");
+    if (M < 0 || N < 0 || K < 0) return fail(MBNB_ERR_ARG, "linear_fp8: negative size");
+    if (M == 0 || N == 0) return MBNB_OK;
+    if (!X || !W || !W_scales || !out) return fail(MBNB_ERR_ARG, "linear_fp8: NULL pointer");
+    set_linear8_workspace(workspace, workspace ? workspace_bytes : 0);
+    const int rc = linear_fp8_dispatch(X, dtype, M, K, W, W_scales, N, bias, out, static_cast<hipStream_t>(stream));
     set_linear8_workspace(nullptr, 0);
     return rc;
 }

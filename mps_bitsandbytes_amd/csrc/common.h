@@ -96,6 +96,55 @@ template <int QT> __device__ __forceinline__ void fill_code_lut(float *lut, int 
     }
 }
 
+// ---------------------------------------------------------------- 8-bit weight formats (W8A16 kernels)
+// WF = 0: row-wise INT8 (functional.py:607-636: value = q * (scale / 127));  WF = 1: the reference's FP8 E4M3
+// (functional.py:1086-1215: value = decode(byte) * scale).  Both are decoded byte by byte inside the GEMM producers.
+constexpr int W8_INT8 = 0, W8_FP8 = 1;
+
+// decoder of functional.py:1178-1215: (1 + m/8) * 2^(e-7); e = 0: (m/8) * 2^-6; 0x7F / 0xFF: NaN
+__device__ __forceinline__ float fp8_e4m3_to_float(uint32_t b) {
+    const uint32_t e = (b >> 3) & 15u, m = b & 7u;
+    uint32_t bits = (e == 0) ? __builtin_bit_cast(uint32_t, (float)m * 0.001953125f) : (((e + 120u) << 23) | (m << 20));
+    if (e == 15u && m == 7u) bits = 0x7FC00000u;
+    return __builtin_bit_cast(float, bits | ((b & 0x80u) << 24));
+}
+
+// floor(torch.log2(a)) for finite a > 0 as the reference's encoder sees it: log2 is correctly rounded, so the
+// exponent already reads k a few f32 ulps below 2^k (oracle/oracle.c fp8_exponent; pinned by tests/golden/g7_fp8.npz)
+__device__ __forceinline__ int fp8_exponent(float a) {
+    const uint32_t u = __builtin_bit_cast(uint32_t, a);
+    const uint32_t ef = (u >> 23) & 0xFFu;
+    if (ef == 0) return -127;
+    int e = (int)ef - 127;
+    const int k = e + 1;
+    const uint32_t n = k >= 9 ? 5u : k >= 5 ? 2u : k >= 3 ? 1u : k >= -1 ? 0u : k >= -3 ? 1u : k >= -7 ? 2u : k >= -15 ? 5u : 11u;
+    if ((0x7FFFFFu - (u & 0x7FFFFFu)) < n) e += 1;
+    return e;
+}
+
+// encoder of functional.py:1106-1163, restated literally (NOT the OCP conversion): no mantissa carry, subnormals
+// flushed to signed zero, biased exponent >= 15 -> 0x77 (so every |v| >= 256 becomes 240), NaN -> 0x7F
+__device__ __forceinline__ uint32_t float_to_fp8_e4m3(float v) {
+    if (v != v) return 0x7Fu;
+    const uint32_t sign = v < 0.0f ? 0x80u : 0u;
+    float a = fminf(fabsf(v), 448.0f);
+    if (a == 0.0f) return sign;
+    const int e = fp8_exponent(a);
+    const int biased = e + 7;
+    if (biased >= 15) return sign | 0x77u;
+    if (biased <= 0) return sign;
+    const float pow2 = __builtin_bit_cast(float, (uint32_t)(e + 127) << 23);
+    float mb = (a / pow2 - 1.0f) * 8.0f + 0.5f;     // division by a power of two: exact
+    mb = fminf(fmaxf(mb, 0.0f), 7.0f);
+    return sign | ((uint32_t)biased << 3) | (uint32_t)mb;
+}
+
+template <int WF> __device__ __forceinline__ float w8_row_scale(float s) { return WF == W8_INT8 ? s / 127.0f : s; }
+template <int WF> __device__ __forceinline__ float w8_decode(uint32_t byte) {   // byte in bits 0..7
+    if constexpr (WF == W8_INT8) return (float)(int)(int8_t)byte;
+    else return fp8_e4m3_to_float(byte & 0xFFu);
+}
+
 // ---------------------------------------------------------------- absmax decode
 struct AbsmaxView {
     const float *f32;

@@ -72,7 +72,7 @@ template <typename T, bool NESTED> struct Q4ProducerRT {
 };
 
 // int8 rowwise weights (Linear8bit)
-template <typename T> struct I8ProducerRT {
+template <typename T, int WF = W8_INT8> struct I8ProducerRT {
     struct Params {
         const int8_t *w;
         const float *scales;
@@ -84,7 +84,7 @@ template <typename T> struct I8ProducerRT {
     };
     static __device__ __forceinline__ void init_lut(float *, int, const Params &) {}
     static __device__ __forceinline__ void fetch(const Params &p, int64_t n, int64_t k, Regs &r) {
-        r.s = p.scales[n] / 127.0f;
+        r.s = w8_row_scale<WF>(p.scales[n]);
         r.w[0] = *reinterpret_cast<const u32x4 *>(p.w + n * p.K_weight + k);
         r.w[1] = *reinterpret_cast<const u32x4 *>(p.w + n * p.K_weight + k + 16);
     }
@@ -93,9 +93,9 @@ template <typename T> struct I8ProducerRT {
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const uint32_t w = r.w[d >> 1][2 * (d & 1) + (j >> 1)];
-            const int q0 = (int)(int8_t)(w >> (16 * (j & 1)));
-            const int q1 = (int)(int8_t)(w >> (16 * (j & 1) + 8));
-            o[j] = pack2<T>((float)q0 * r.s, (float)q1 * r.s);
+            const float q0 = w8_decode<WF>(w >> (16 * (j & 1)));
+            const float q1 = w8_decode<WF>(w >> (16 * (j & 1) + 8));
+            o[j] = pack2<T>(q0 * r.s, q1 * r.s);
         }
         *reinterpret_cast<u32x4 *>(tile + swz_off(row, chunk)) = o;
     }

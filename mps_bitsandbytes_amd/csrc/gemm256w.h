@@ -12,8 +12,8 @@
 
 namespace mbnb {
 
-template <typename T>
-__global__ __launch_bounds__(512, 2) void k_gemm256w(const T *__restrict__ X, typename I8ProducerRT<T>::Params wp,
+template <typename T, int WF = W8_INT8>
+__global__ __launch_bounds__(512, 2) void k_gemm256w(const T *__restrict__ X, typename I8ProducerRT<T, WF>::Params wp,
                                                      const T *__restrict__ bias, void *__restrict__ out_v, int out_dtype,
                                                      int64_t M, int64_t N, int64_t K) {
     using Frag = typename Mfma<T>::frag;
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm256w(const T *__restrict__ X, ty
     int64_t bn = n0 + b_row;
     bn = bn < N ? bn : N - 1;
     const int8_t *w_src = wp.w + bn * wp.K_weight + 32 * b_half;
-    const float sc = wp.scales[bn] / 127.0f;   // dequantize_rowwise: q.float() * (scales / 127.0)
+    const float sc = w8_row_scale<WF>(wp.scales[bn]);   // int8: q.float() * (scales / 127.0); fp8: decode(byte) * scale
     auto issue_raw = [&](int rs, int64_t k0) {
 #pragma unroll
         for (int h = 0; h < 2; h++) {
@@ -94,8 +94,8 @@ __global__ __launch_bounds__(512, 2) void k_gemm256w(const T *__restrict__ X, ty
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const uint32_t w = r[d >> 1][2 * (d & 1) + (j >> 1)];
-            const float q0 = (float)(int)(int8_t)(w >> (16 * (j & 1)));
-            const float q1 = (float)(int)(int8_t)(w >> (16 * (j & 1) + 8));
+            const float q0 = w8_decode<WF>(w >> (16 * (j & 1)));
+            const float q1 = w8_decode<WF>(w >> (16 * (j & 1) + 8));
             o[j] = pack2<T>(q0 * sc, q1 * sc);
         }
         *reinterpret_cast<u32x4 *>(smem + stage * P_IMG + bw_off[d]) = o;

@@ -101,7 +101,7 @@ template <typename T, int QT, bool NESTED> struct Q4Producer {
 };
 
 // int8 rowwise weights (Linear8bit): value = round_T( (float)q * (scale[n] / 127) ), nn/linear8bit.py:76-80
-template <typename T> struct I8Producer {
+template <typename T, int WF = W8_INT8> struct I8Producer {
     struct Params {
         const int8_t *w;      // [N, K]
         const float *scales;  // [N]
@@ -114,7 +114,7 @@ template <typename T> struct I8Producer {
     static __device__ __forceinline__ void init_lut(float *, int) {}
     static __device__ __forceinline__ void fetch(const Params &p, int64_t n, int64_t k, Regs &r) {
         if (n < p.N) {
-            r.s = p.scales[n] / 127.0f;
+            r.s = w8_row_scale<WF>(p.scales[n]);
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 const int64_t kk = k + 16 * h;
@@ -140,8 +140,8 @@ template <typename T> struct I8Producer {
             for (int j = 0; j < 4; j++) {
                 // 8 int8 per output chunk: dwords 2*(d&1), 2*(d&1)+1 of half d>>1
                 const uint32_t w = r.w[d >> 1][2 * (d & 1) + (j >> 1)];
-                const int q0 = (int)(int8_t)(w >> (16 * (j & 1)));
-                const int q1 = (int)(int8_t)(w >> (16 * (j & 1) + 8));
+                const float q0 = w8_decode<WF>(w >> (16 * (j & 1)));
+                const float q1 = w8_decode<WF>(w >> (16 * (j & 1) + 8));
                 o[j] = pack2<T>((float)q0 * r.s, (float)q1 * r.s);
             }
             *reinterpret_cast<u32x4 *>(tile + swz_off(row, chunk0 + d)) = o;

@@ -410,7 +410,7 @@ int matmul_int8_dispatch(const int8_t *A, const int8_t *B, const float *sA, cons
 }
 
 // ------------------------------------------------------------------ linear_int8 (W8A16)
-template <typename T>
+template <typename T, int WF = W8_INT8>
 __global__ __launch_bounds__(256) void k_linear_i8_generic(const T *__restrict__ X, const int8_t *__restrict__ W,
                                                           const float *__restrict__ scales, const T *__restrict__ bias,
                                                           T *__restrict__ out, int64_t M, int64_t N, int64_t K) {
@@ -418,10 +418,10 @@ __global__ __launch_bounds__(256) void k_linear_i8_generic(const T *__restrict__
     const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t m = blockIdx.y;
     if (n >= N) return;
-    const float s = scales[n] / 127.0f;
+    const float s = w8_row_scale<WF>(scales[n]);
     float acc = 0.0f;
     for (int64_t k = lane; k < K; k += 64) {
-        const float w = to_f32(from_f32<T>((float)W[n * K + k] * s));
+        const float w = to_f32(from_f32<T>(w8_decode<WF>((uint32_t)(uint8_t)W[n * K + k]) * s));
         acc = fmaf(to_f32(X[m * K + k]), w, acc);
     }
     acc = wave_sum(acc);
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(256) void k_linear_i8_generic(const T *__restrict__
 // Lane quarter q owns k in [32q, 32q+32) of a block: 32 weight bytes = two 16-byte loads; bytes 8g .. 8g+7 are the A
 // fragment of MFMA g after sign-extend -> * (scale/127) -> RNE 16 bit (dequantize_rowwise bits); the activation
 // fragment of MFMA g is the 16 bytes at k = 32q + 8g.  Partial tiles are added in wave order through LDS.
-template <typename T, int MT>
+template <typename T, int MT, int WF = W8_INT8>
 __global__ __launch_bounds__(1024) void k_skinny8(const T *__restrict__ X, const int8_t *__restrict__ W, const float *__restrict__ scales,
                                                  const T *__restrict__ bias, T *__restrict__ out, int64_t M, int64_t N, int64_t K) {
     constexpr int WV = 16;
@@ -446,7 +446,7 @@ __global__ __launch_bounds__(1024) void k_skinny8(const T *__restrict__ X, const
     int64_t nrow = n0 + r16;
     nrow = nrow < N ? nrow : N - 1;
     const int8_t *wrow = W + nrow * K;
-    const float sc = scales[nrow] / 127.0f;
+    const float sc = w8_row_scale<WF>(scales[nrow]);
     const T *xrow[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; mt++) {
@@ -483,8 +483,8 @@ __global__ __launch_bounds__(1024) void k_skinny8(const T *__restrict__ X, const
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const uint32_t wd = w[g >> 1][2 * (g & 1) + (j >> 1)];
-                const float q0 = (float)(int)(int8_t)(wd >> (16 * (j & 1)));
-                const float q1 = (float)(int)(int8_t)(wd >> (16 * (j & 1) + 8));
+                const float q0 = w8_decode<WF>(wd >> (16 * (j & 1)));
+                const float q1 = w8_decode<WF>(wd >> (16 * (j & 1) + 8));
                 fr[j] = pack2<T>(q0 * sc, q1 * sc);
             }
             const auto af = __builtin_bit_cast(typename Mfma16<T>::frag, fr);
@@ -519,7 +519,7 @@ void set_linear8_workspace(void *ws, int64_t bytes) {
 }
 int64_t matmul4_splitk_slices(int64_t M, int64_t N, int64_t K);
 
-template <typename T>
+template <typename T, int WF = W8_INT8>
 static int launch_linear_int8(const void *X, int64_t M, int64_t K, const int8_t *W, const float *scales, int64_t N,
                               const void *bias, void *out, hipStream_t st) {
     const T *x = static_cast<const T *>(X);
@@ -531,27 +531,27 @@ static int launch_linear_int8(const void *X, int64_t M, int64_t K, const int8_t 
 #define MBNB_SKINNY8(MT)                                                                                            \
     do {                                                                                                            \
         constexpr int lds = 16 * MT * 1024;                                                                         \
-        hipLaunchKernelGGL((k_skinny8<T, MT>), dim3(grid), dim3(1024), lds, st, x, W, scales, b, o, M, N, K);       \
+        hipLaunchKernelGGL((k_skinny8<T, MT, WF>), dim3(grid), dim3(1024), lds, st, x, W, scales, b, o, M, N, K);       \
     } while (0)
             if (M <= 16) MBNB_SKINNY8(1);
             else if (M <= 32) MBNB_SKINNY8(2);
             else MBNB_SKINNY8(4);
 #undef MBNB_SKINNY8
-            set_kernel_name("w8a16_skinny");
+            set_kernel_name(WF == W8_INT8 ? "w8a16_skinny" : "fp8a16_skinny");
             return check_launch("linear_int8(skinny)");
         }
         const bool fast = (K % 16 == 0) && (((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(W)) & 15) == 0) && M > 4;
         if (fast && (K % 64 == 0) && ((M + 255) / 256) * ((N + 255) / 256) >= 96) {
             // large problems: the 256 x 256 one-workgroup-per-CU kernel with the int8 -> 16-bit decode in the
             // weight-tile producer (gemm256.h, k_gemm256)
-            using P = I8ProducerRT<T>;
+            using P = I8ProducerRT<T, WF>;
             typename P::Params wp{W, scales, N, K};
             const int64_t tiles = ((M + 255) / 256) * ((N + 255) / 256);
             const int od = std::is_same<T, f16_t>::value ? MBNB_F16 : MBNB_BF16;
             static const bool old_w8 = getenv("MBNB_W8_REGSTAGED") != nullptr;   // A/B switch: register-staged k_gemm256
             if (!old_w8 && ((reinterpret_cast<uintptr_t>(W) & 15) == 0)) {
                 // LDS-DMA pipeline (gemm256w.h): activations and raw int8 weights by global_load_lds
-                auto kw = k_gemm256w<T>;
+                auto kw = k_gemm256w<T, WF>;
                 constexpr int ldsw = gemm256w_lds_bytes();
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kw), hipFuncAttributeMaxDynamicSharedMemorySize, ldsw);
                 if (e != hipSuccess) {
@@ -559,7 +559,7 @@ static int launch_linear_int8(const void *X, int64_t M, int64_t K, const int8_t 
                     return (int)e;
                 }
                 hipLaunchKernelGGL(kw, dim3((unsigned)tiles), dim3(512), ldsw, st, x, wp, b, static_cast<void *>(o), od, M, N, K);
-                set_kernel_name("w8a16_mfma256");
+                set_kernel_name(WF == W8_INT8 ? "w8a16_mfma256" : "fp8a16_mfma256");
                 return check_launch("linear_int8(mfma256w)");
             }
             auto kern = k_gemm256<T, P>;
@@ -570,11 +570,11 @@ static int launch_linear_int8(const void *X, int64_t M, int64_t K, const int8_t 
                 return (int)e;
             }
             hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(512), G256_LDS, st, x, wp, b, static_cast<void *>(o), od, M, N, K);
-            set_kernel_name("w8a16_mfma256");
+            set_kernel_name(WF == W8_INT8 ? "w8a16_mfma256" : "fp8a16_mfma256");
             return check_launch("linear_int8(mfma256)");
         }
         if (fast) {
-            using P = I8Producer<T>;
+            using P = I8Producer<T, WF>;
             typename P::Params wp{W, scales, N, K};
             constexpr int BM = 128, BN = 128;
             constexpr int lds = gemm_decode_lds_bytes<BM, BN>();
@@ -595,17 +595,17 @@ static int launch_linear_int8(const void *X, int64_t M, int64_t K, const int8_t 
                 if (rc) return rc;
                 hipLaunchKernelGGL((k_splitk_reduce<T, T>), dim3((unsigned)(tiles * 16)), dim3(256), 0, st, tls_ws8, (int)slices, b, o,
                                    M, N, (M + BM - 1) / BM, tiles);
-                set_kernel_name("w8a16_mfma128_splitk");
+                set_kernel_name(WF == W8_INT8 ? "w8a16_mfma128_splitk" : "fp8a16_mfma128_splitk");
                 return check_launch("linear_int8(split-K reduce)");
             }
             hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, st, x, wp, b, o, M, N, K, static_cast<float *>(nullptr), (int64_t)0);
-            set_kernel_name("w8a16_mfma128");
+            set_kernel_name(WF == W8_INT8 ? "w8a16_mfma128" : "fp8a16_mfma128");
             return check_launch("linear_int8(mfma)");
         }
     }
-    hipLaunchKernelGGL(k_linear_i8_generic<T>, dim3((unsigned)((N + 3) / 4), (unsigned)M), dim3(256), 0, st, x, W, scales,
+    hipLaunchKernelGGL((k_linear_i8_generic<T, WF>), dim3((unsigned)((N + 3) / 4), (unsigned)M), dim3(256), 0, st, x, W, scales,
                        b, o, M, N, K);
-    set_kernel_name("w8a16_generic");
+    set_kernel_name(WF == W8_INT8 ? "w8a16_generic" : "fp8a16_generic");
     return check_launch("linear_int8(generic)");
 }
 
@@ -615,6 +615,17 @@ int linear_int8_dispatch(const void *X, int dtype, int64_t M, int64_t K, const i
         case MBNB_F16: return launch_linear_int8<f16_t>(X, M, K, W, scales, N, bias, out, st);
         case MBNB_BF16: return launch_linear_int8<bf16_t>(X, M, K, W, scales, N, bias, out, st);
         default: return launch_linear_int8<float>(X, M, K, W, scales, N, bias, out, st);
+    }
+}
+
+// LinearFP8.forward / matmul_fp8_e4m3 (functional.py:796-807): the same W8A16 kernels with the FP8 byte decoder
+int linear_fp8_dispatch(const void *X, int dtype, int64_t M, int64_t K, const uint8_t *W, const float *scales, int64_t N,
+                        const void *bias, void *out, hipStream_t st) {
+    const int8_t *w = reinterpret_cast<const int8_t *>(W);
+    switch (dtype) {
+        case MBNB_F16: return launch_linear_int8<f16_t, W8_FP8>(X, M, K, w, scales, N, bias, out, st);
+        case MBNB_BF16: return launch_linear_int8<bf16_t, W8_FP8>(X, M, K, w, scales, N, bias, out, st);
+        default: return launch_linear_int8<float, W8_FP8>(X, M, K, w, scales, N, bias, out, st);
     }
 }
 

@@ -314,6 +314,73 @@ __global__ __launch_bounds__(256) void k_quantize_rowwise(const T *__restrict__ 
     for (int64_t c = nvec * 8 + threadIdx.x; c < cols; c += 256) orow[c] = quant_i8(to_f32(row[c]), s);
 }
 
+// ---------------------------------------------------------------------------------------------
+// FP8 E4M3, the reference's own format (functional.py:643-673, :1086-1215; common.h float_to_fp8_e4m3 /
+// fp8_e4m3_to_float): scales[r] = clamp(max|row| / 448, 1e-12); byte = encode(clamp(x / scale, +-448)).
+// One workgroup per row, 8 values per thread and trip; a NaN in the row propagates into the scale as torch.max does.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_quantize_fp8(const T *__restrict__ A, int64_t rows, int64_t cols,
+                                                     uint8_t *__restrict__ out, float *__restrict__ scales, bool vec_ok) {
+    __shared__ float red[8];
+    const int64_t r = blockIdx.x;
+    const T *row = A + r * cols;
+    float am = 0.0f, nan = 0.0f;
+    const int64_t nvec = vec_ok ? cols / 8 : 0;
+    for (int64_t g = threadIdx.x; g < nvec; g += 256) {
+        float x[8];
+        load8<T>(A, rows, cols, r, g * 8, true, x);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            am = fmaxf(am, fabsf(x[j]));
+            nan = (x[j] != x[j]) ? 1.0f : nan;
+        }
+    }
+    for (int64_t c = nvec * 8 + threadIdx.x; c < cols; c += 256) {
+        const float v = to_f32(row[c]);
+        am = fmaxf(am, fabsf(v));
+        nan = (v != v) ? 1.0f : nan;
+    }
+    am = wave_max(am);
+    nan = wave_max(nan);
+    if ((threadIdx.x & 63) == 0) {
+        red[threadIdx.x >> 6] = am;
+        red[4 + (threadIdx.x >> 6)] = nan;
+    }
+    __syncthreads();
+    am = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    nan = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+    float s = fmaxf(am / 448.0f, 1e-12f);
+    if (nan > 0.0f) s = __builtin_bit_cast(float, 0x7FC00000u);
+    if (threadIdx.x == 0) scales[r] = s;
+    uint8_t *orow = out + r * cols;
+    auto enc = [&](float v) {
+        float n = v / s;                                   // true division, as the reference
+        n = (n < -448.0f) ? -448.0f : ((n > 448.0f) ? 448.0f : n);   // clamp keeps NaN
+        return float_to_fp8_e4m3(n);
+    };
+    for (int64_t g = threadIdx.x; g < nvec; g += 256) {
+        float x[8];
+        load8<T>(A, rows, cols, r, g * 8, true, x);
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            lo |= enc(x[j]) << (8 * j);
+            hi |= enc(x[4 + j]) << (8 * j);
+        }
+        *reinterpret_cast<u32x2 *>(orow + g * 8) = u32x2{lo, hi};
+    }
+    for (int64_t c = nvec * 8 + threadIdx.x; c < cols; c += 256) orow[c] = (uint8_t)enc(to_f32(row[c]));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_dequantize_fp8(const uint8_t *__restrict__ q, const float *__restrict__ scales,
+                                                       int64_t rows, int64_t cols, T *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols) return;
+    out[i] = from_f32<T>(fp8_e4m3_to_float(q[i]) * scales[i / cols]);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_dequantize_rowwise(const int8_t *__restrict__ q,
                                                            const float *__restrict__ scales, int64_t rows,
@@ -475,6 +542,28 @@ int quantize_rowwise_dispatch(const void *A, int dtype, int64_t rows, int64_t co
         default: hipLaunchKernelGGL(k_quantize_rowwise<float>, dim3(grid), dim3(256), 0, st, static_cast<const float *>(A), rows, cols, out, scales, vec_ok); break;
     }
     return check_launch("quantize_rowwise");
+}
+
+int quantize_fp8_dispatch(const void *A, int dtype, int64_t rows, int64_t cols, uint8_t *out, float *scales, hipStream_t st) {
+    const bool vec_ok = (cols % 8 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && ((reinterpret_cast<uintptr_t>(out) & 7) == 0);
+    const unsigned grid = (unsigned)rows;
+    switch (dtype) {
+        case MBNB_F16: hipLaunchKernelGGL(k_quantize_fp8<f16_t>, dim3(grid), dim3(256), 0, st, static_cast<const f16_t *>(A), rows, cols, out, scales, vec_ok); break;
+        case MBNB_BF16: hipLaunchKernelGGL(k_quantize_fp8<bf16_t>, dim3(grid), dim3(256), 0, st, static_cast<const bf16_t *>(A), rows, cols, out, scales, vec_ok); break;
+        default: hipLaunchKernelGGL(k_quantize_fp8<float>, dim3(grid), dim3(256), 0, st, static_cast<const float *>(A), rows, cols, out, scales, vec_ok); break;
+    }
+    return check_launch("quantize_fp8_e4m3");
+}
+
+int dequantize_fp8_dispatch(const uint8_t *q, const float *scales, int64_t rows, int64_t cols, int out_dtype, void *out,
+                            hipStream_t st) {
+    const unsigned grid = (unsigned)((rows * cols + 255) / 256);
+    switch (out_dtype) {
+        case MBNB_F16: hipLaunchKernelGGL(k_dequantize_fp8<f16_t>, dim3(grid), dim3(256), 0, st, q, scales, rows, cols, static_cast<f16_t *>(out)); break;
+        case MBNB_BF16: hipLaunchKernelGGL(k_dequantize_fp8<bf16_t>, dim3(grid), dim3(256), 0, st, q, scales, rows, cols, static_cast<bf16_t *>(out)); break;
+        default: hipLaunchKernelGGL(k_dequantize_fp8<float>, dim3(grid), dim3(256), 0, st, q, scales, rows, cols, static_cast<float *>(out)); break;
+    }
+    return check_launch("dequantize_fp8_e4m3");
 }
 
 int dequantize_rowwise_dispatch(const int8_t *q, const float *scales, int64_t rows, int64_t cols, int out_dtype,

@@ -574,6 +574,70 @@ def linear_int8(input: Tensor, weight_int8: Tensor, weight_scales: Tensor, bias:
     return out.reshape(*input.shape[:-1], N)
 
 
+# ============================================================================= FP8 E4M3 (the reference's own format)
+def quantize_fp8_e4m3(tensor: Tensor) -> Tuple[Tensor, Tensor]:
+    """
+    Row-wise FP8 E4M3 quantization in the reference's format (functional.py:643-663, encoder :1086-1163), bit-exact:
+    returns (uint8 [rows, cols], scales f32 [rows]) with scales = clamp(max|row| / 448, 1e-12).  The encoder is the
+    reference's, not the OCP conversion (no mantissa carry, subnormals flushed, |v| >= 256 saturates to 240).
+    """
+    if tensor.dim() != 2:
+        raise ValueError("Input must be 2D")
+    _check_device(tensor, "quantize_fp8_e4m3")
+    A = tensor if tensor.dtype in _native.DTYPE_CODE else tensor.float()
+    A = A.contiguous()
+    rows, cols = A.shape
+    out = torch.empty(rows, cols, dtype=torch.uint8, device=A.device)
+    scales = torch.empty(rows, dtype=torch.float32, device=A.device)
+    with torch.cuda.device(A.device):
+        check(_native.lib().mbnb_quantize_fp8_e4m3(ptr(A), dtype_code(A.dtype, "quantize_fp8_e4m3"), rows, cols, ptr(out),
+                                                   ptr(scales), stream_ptr(A.device)), "quantize_fp8_e4m3")
+    return out, scales
+
+
+def dequantize_fp8_e4m3(quantized: Tensor, scales: Tensor, dtype: torch.dtype = torch.float16) -> Tensor:
+    """decode(byte) * scales[row] -> dtype (functional.py:666-673, decoder :1166-1215), bit-exact."""
+    _check_device(quantized, "dequantize_fp8_e4m3")
+    q = quantized.contiguous()
+    rows, cols = q.shape
+    s = scales.to(device=q.device, dtype=torch.float32).contiguous()
+    out = torch.empty(rows, cols, dtype=dtype, device=q.device)
+    with torch.cuda.device(q.device):
+        check(_native.lib().mbnb_dequantize_fp8_e4m3(ptr(q), ptr(s), rows, cols, dtype_code(dtype, "dequantize_fp8_e4m3"),
+                                                     ptr(out), stream_ptr(q.device)), "dequantize_fp8_e4m3")
+    return out
+
+
+def matmul_fp8_e4m3(input: Tensor, weight: Tensor, weight_scales: Tensor, bias: Optional[Tensor] = None,
+                    dtype: torch.dtype = torch.float16) -> Tensor:
+    """
+    ``input[..., K] @ dequantize_fp8_e4m3(weight[N, K], weight_scales, dtype)^T + bias`` (functional.py:796-807) in one
+    kernel: the W8A16 GEMMs of linear_int8 with the FP8 byte decoder in the weight producer.
+    """
+    _check_device(input, "matmul_fp8_e4m3")
+    _check_device(weight, "matmul_fp8_e4m3")
+    dcode = dtype_code(dtype, "matmul_fp8_e4m3")
+    N, K = weight.shape
+    is_1d = input.dim() == 1
+    x = (input.unsqueeze(0) if is_1d else input)
+    if x.shape[-1] != K:
+        raise RuntimeError(f"matmul_fp8_e4m3: input width {x.shape[-1]} does not match weight {tuple(weight.shape)}")
+    lead = x.shape[:-1]
+    x2 = x.reshape(-1, K).to(dtype).contiguous()
+    M = x2.shape[0]
+    w = weight.contiguous()
+    s = weight_scales.to(device=x2.device, dtype=torch.float32).contiguous()
+    b = None if bias is None else bias.to(device=x2.device, dtype=dtype).contiguous()
+    out = torch.empty(M, N, dtype=dtype, device=x2.device)
+    ws_bytes = int(_native.lib().mbnb_matmul_4bit_workspace_bytes(M, N, K)) if M > 64 else 0
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x2.device) if ws_bytes > 0 else None
+    with torch.cuda.device(x2.device):
+        check(_native.lib().mbnb_linear_fp8(ptr(x2), dcode, M, K, ptr(w), ptr(s), N, ptr(b), ptr(out), ptr(ws), ws_bytes,
+                                            stream_ptr(x2.device)), "matmul_fp8_e4m3")
+    out = out.reshape(*lead, N)
+    return out.squeeze(0) if is_1d else out
+
+
 # ============================================================================= quantized embedding lookups
 def embedding_4bit(input: Tensor, weight_packed: Tensor, weight_absmax: Tensor, embedding_dim: int,
                    blocksize: int = 64, quant_type: str = 'nf4', padding_idx: Optional[int] = None,

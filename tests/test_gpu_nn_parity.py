@@ -147,3 +147,72 @@ def test_outlier_linear_vs_oracle(M, K, N, dt, n_out, bias):
     ref = oracle.outlier_linear(x[rows], q, s, oidx, ow, b)
     err = rel_fro(y.cpu()[rows], ref)
     assert err <= OA_TOL[dt], err
+
+
+# --------------------------------------------------------------------------- FP8 E4M3
+@pytest.fixture(scope="module")
+def g7():
+    with open(os.path.join(HERE, "manifest_fp8.json")) as f:
+        cases = json.load(f)["g7"]
+    return cases, np.load(os.path.join(HERE, "g7_fp8.npz"))
+
+
+def test_fp8_quantize_dequantize_golden_bit_exact(g7):
+    """The reference's encoder incl. its exponent rule just below powers of two, clamps, zeros, and its decoder."""
+    cases, z = g7
+    for c in [c for c in cases if c["kind"] == "quant"]:
+        n = c["name"]
+        x = from_bits(z[f"q_{n}_x"], DT[c["dtype"]]).reshape(c["shape"])
+        q, s = bnb.quantize_fp8_e4m3(x.to(DEV))
+        assert n_mismatch(q.cpu(), from_bits(z[f"q_{n}_q"]).reshape(c["shape"])) == 0, n
+        assert bits_equal(s.cpu(), from_bits(z[f"q_{n}_s"])), n
+        for dt in ("f16", "bf16", "f32"):
+            deq = bnb.dequantize_fp8_e4m3(q, s, DT[dt])
+            assert n_mismatch(deq.cpu(), from_bits(z[f"q_{n}_deq_{dt}"], DT[dt]).reshape(c["shape"])) == 0, (n, dt)
+    allb = torch.arange(256, dtype=torch.uint8).reshape(2, 128)
+    got = bnb.dequantize_fp8_e4m3(allb.to(DEV), torch.tensor([1.0, 0.37], device=DEV), torch.float32).cpu()
+    ref = from_bits(z["dec_all"]).reshape(2, 128)
+    assert bool(((got.view(torch.int32) == ref.view(torch.int32)) | (torch.isnan(got) & torch.isnan(ref))).all())
+
+
+def test_fp8_quantize_full_size_vs_oracle():
+    for dt, std in ((torch.float16, 1.0), (torch.bfloat16, 0.02), (torch.float32, 30.0)):
+        x = synthetic.normal((2048, 4096), dt, seed=931, std=std)
+        q, s = bnb.quantize_fp8_e4m3(x.to(DEV))
+        oq, os_ = oracle.quantize_fp8_e4m3(x)
+        assert n_mismatch(q.cpu(), oq) == 0 and bits_equal(s.cpu(), os_)
+        assert n_mismatch(bnb.dequantize_fp8_e4m3(q, s, dt).cpu(), oracle.dequantize_fp8_e4m3(oq, os_, dt)) == 0
+
+
+def test_linear_fp8_golden(g7):
+    cases, z = g7
+    for c in [c for c in cases if c["kind"] == "linear_fp8"]:
+        i, dt = c["id"], DT[c["dtype"]]
+        lin = torch.nn.Linear(c["K"], c["N"], bias=c["bias"]).to(dt)
+        lin.weight.data.copy_(from_bits(z[f"l{i}_W"], dt).reshape(c["N"], c["K"]))
+        if c["bias"]:
+            lin.bias.data.copy_(from_bits(z[f"l{i}_bias"], dt))
+        l8 = bnb.LinearFP8.from_linear(lin.to(DEV))
+        assert sorted(l8.state_dict().keys()) == c["state_keys"]
+        assert n_mismatch(l8.weight_fp8.cpu(), from_bits(z[f"l{i}_q"]).reshape(c["N"], c["K"])) == 0
+        assert bits_equal(l8.weight_scales.cpu(), from_bits(z[f"l{i}_s"]))
+        x = from_bits(z[f"l{i}_x"], dt).reshape(*c["M"], c["K"])
+        y = l8(x.to(DEV))
+        ref = from_bits(z[f"l{i}_y"], dt).reshape(*c["M"], c["N"])
+        assert y.shape == ref.shape and y.dtype == dt
+        assert rel_fro(y.cpu(), ref) <= (2e-4 if dt == torch.float16 else 2e-3), (c, rel_fro(y.cpu(), ref))
+
+
+@pytest.mark.parametrize("M,N,K,dt,kern", [(1, 4096, 4096, torch.bfloat16, "fp8a16_skinny"), (33, 1000, 384, torch.float16, "fp8a16_skinny"),
+                                            (300, 1000, 1024, torch.float16, "fp8a16_mfma128_splitk"), (200, 384, 80, torch.bfloat16, "fp8a16_mfma128"),
+                                            (2560, 2560, 256, torch.bfloat16, "fp8a16_mfma256"), (3, 50, 20, torch.float16, "fp8a16_generic")])
+def test_linear_fp8_kernels_vs_oracle(M, N, K, dt, kern):
+    W = synthetic.normal((N, K), dt, seed=941, std=0.05)
+    q, s = oracle.quantize_fp8_e4m3(W)
+    x = synthetic.normal((M, K), dt, seed=942)
+    b = synthetic.normal((N,), dt, seed=943)
+    y = bnb.matmul_fp8_e4m3(x.to(DEV), q.to(DEV), s.to(DEV), b.to(DEV), dt)
+    assert _native.last_kernel() == kern
+    rows = torch.arange(0, M, max(1, M // 64))[:64]
+    ref = oracle.linear_fp8(x[rows], q, s, b)
+    assert rel_fro(y.cpu()[rows], ref) <= (2e-4 if dt == torch.float16 else 2e-3)

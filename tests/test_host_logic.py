@@ -170,3 +170,16 @@ def test_embedding_and_outlier_modules_mirror_reference_without_a_gpu():
                lambda: bnb.OutlierAwareLinear.from_linear(torch.nn.Linear(64, 8).half())):
         with pytest.raises(ValueError, match="requires tensor on a 'cuda'"):
             fn()
+
+
+def test_linear_fp8_module_mirrors_reference_without_a_gpu():
+    l = bnb.LinearFP8(64, 32, bias=True, compute_dtype=torch.bfloat16)
+    assert sorted(l.state_dict()) == ["bias", "weight_fp8", "weight_scales"]
+    assert l.weight_fp8.dtype == torch.uint8 and l.weight_fp8.shape == (32, 64) and l.bias.dtype == torch.bfloat16
+    assert "quant_type=fp8_e4m3" in l.extra_repr() and bnb.LinearFP8(8, 4, bias=False).bias is None
+    with pytest.raises(ValueError, match="Input must be 2D"):
+        bnb.quantize_fp8_e4m3(torch.zeros(4))
+    for fn in (lambda: bnb.quantize_fp8_e4m3(torch.zeros(4, 8)), lambda: l(torch.zeros(2, 64)),
+               lambda: bnb.LinearFP8.from_linear(torch.nn.Linear(64, 8).half())):
+        with pytest.raises(ValueError, match="requires tensor on a 'cuda'"):
+            fn()
