@@ -43,9 +43,9 @@ def parse():
     ap.add_argument("--no-empirical", action="store_true", help="skip the vendor-BLAS / copy-bandwidth context figures")
     ap.add_argument("--warmup", type=int, default=100)  # ~13 ms: the GPU clock needs a few ms of load to ramp
     ap.add_argument("--workload", default="nf4_m4096",
-                    choices=["nf4_m4096", "nf4dq_ffn", "int8_4096", "nf4_m1", "embed4", "embed8", "outlier"],
+                    choices=["nf4_m4096", "nf4dq_ffn", "int8_4096", "nf4_m1", "embed4", "embed8", "outlier", "w8a16", "fp8"],
                     help="nf4_m4096 = the BASELINE metric (default); nf4dq_ffn / int8_4096 / nf4_m1 = BASELINE configs 3, 4, 2; "
-                         "embed4 / embed8 / outlier = the SURVEY 8f rank-3 rows (single GPU)")
+                         "embed4 / embed8 / outlier = the SURVEY 8f rank-3 rows; w8a16 / fp8 = Linear8bit / LinearFP8 forward (single GPU)")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the output all-gather (GEMM-only scaling)")
     ap.add_argument("--sync-gather", action="store_true", help="N>1: blocking all-gather after every GEMM (no overlap); "
                     "with --no-gather and the default these are the three curves of SURVEY 8e")
@@ -121,6 +121,45 @@ def bench_nn(args, wl, dev, bnb, synthetic):
             dtc = (time.perf_counter() - t0) / n
             out["cpu_baseline"] = {"value": round(nbytes / dtc / 1e9, 2), "unit": "GB/s", "cores": oracle.num_threads(),
                                    "kind": "port", "sample": f"{n} x the full step on the host (oracle, OpenMP)"}
+        return out
+    if wl in ("w8a16", "fp8"):
+        # Linear8bit / LinearFP8 forward at the metric shape: 16-bit activations x 8-bit weights decoded in the GEMM
+        M = N = K = 4096
+        dt = torch.bfloat16
+        lin = torch.nn.Linear(K, N, bias=False)
+        lin.weight.data.copy_(synthetic.normal((N, K), torch.float32, seed=1234, std=0.02))
+        layer = (bnb.Linear8bit if wl == "w8a16" else bnb.LinearFP8).from_linear(lin.to(dt).to(dev))
+        x = synthetic.normal((M, K), dt, seed=4321).to(dev)
+        step = lambda: layer(x)
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        kern_ms = event_time_ms(step, args.steps)
+        flops = 2.0 * M * N * K
+        tf = flops / (kern_ms * 1e-3) / 1e12
+        name = "Linear8bit (row-wise INT8 weights)" if wl == "w8a16" else "LinearFP8 (E4M3 weights, reference format)"
+        out.update({"metric": f"effective bf16 TFLOPS, {name} forward 4096x4096 @ M=4096", "value": round(flops / (elapsed / args.steps) / 1e12, 1),
+                    "unit": "TFLOP/s", "ms_per_step": round(elapsed / args.steps * 1e3, 5), "dtype": "bf16",
+                    "config": {"workload": f"{name}.forward, bf16 activations, weights decoded inside the 256 x 256 LDS-DMA GEMM", "M": M, "N": N, "K": K,
+                               "kernel": __import__("mps_bitsandbytes_amd")._native.last_kernel()},
+                    "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s",
+                                 "frac": round(tf / PEAK_TFLOPS["bf16"], 4), "traffic": None, "kernel_us": round(kern_ms * 1e3, 2)}})
+        if not args.no_cpu_baseline:
+            rows = 256
+            xs = x[:rows].cpu()
+            if wl == "w8a16":
+                q, sc = layer.weight_int8.cpu(), layer.weight_scales.cpu()
+                t0 = time.perf_counter(); oracle.linear_int8(xs, q, sc); dtc = time.perf_counter() - t0
+            else:
+                q, sc = layer.weight_fp8.cpu(), layer.weight_scales.cpu()
+                t0 = time.perf_counter(); oracle.linear_fp8(xs, q, sc); dtc = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": round(2.0 * rows * N * K / dtc / 1e12, 4), "unit": "TFLOP/s", "cores": oracle.num_threads(),
+                                   "kind": "port", "sample": f"{rows} of the {M} rows, one pass (oracle, OpenMP)"}
         return out
     M = N = K = 4096
     dt, n_out = torch.float16, 16
@@ -214,7 +253,7 @@ def main():
     _native.lib()  # fail loudly when the HIP library is missing
 
     wl = args.workload
-    if wl in ("embed4", "embed8", "outlier"):
+    if wl in ("embed4", "embed8", "outlier", "w8a16", "fp8"):
         if rank == 0:
             print(json.dumps(bench_nn(args, wl, dev, bnb, synthetic)))
         return

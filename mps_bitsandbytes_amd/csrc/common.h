@@ -103,10 +103,14 @@ constexpr int W8_INT8 = 0, W8_FP8 = 1;
 
 // decoder of functional.py:1178-1215: (1 + m/8) * 2^(e-7); e = 0: (m/8) * 2^-6; 0x7F / 0xFF: NaN
 __device__ __forceinline__ float fp8_e4m3_to_float(uint32_t b) {
-    const uint32_t e = (b >> 3) & 15u, m = b & 7u;
-    uint32_t bits = (e == 0) ? __builtin_bit_cast(uint32_t, (float)m * 0.001953125f) : (((e + 120u) << 23) | (m << 20));
-    if (e == 15u && m == 7u) bits = 0x7FC00000u;
-    return __builtin_bit_cast(float, bits | ((b & 0x80u) << 24));
+    // (sign | e << 23 | m << 20) read as f32 is (1 + m/8) * 2^(e-127) -- or the f32 subnormal m * 2^-129 for e = 0 --
+    // so one multiply by 2^120 yields (1 + m/8) * 2^(e-7) and (m/8) * 2^-6 alike (f32 denormals are not flushed).
+    // Upper bits of `b` are ignored.
+    const uint32_t t = b << 24;
+    const uint32_t u = (t & 0x80000000u) | ((t >> 4) & 0x07F00000u);
+    float f = __builtin_bit_cast(float, u) * 0x1p120f;
+    if ((t & 0x7F000000u) == 0x7F000000u) f = __builtin_bit_cast(float, 0x7FC00000u);
+    return f;
 }
 
 // floor(torch.log2(a)) for finite a > 0 as the reference's encoder sees it: log2 is correctly rounded, so the
@@ -142,7 +146,7 @@ __device__ __forceinline__ uint32_t float_to_fp8_e4m3(float v) {
 template <int WF> __device__ __forceinline__ float w8_row_scale(float s) { return WF == W8_INT8 ? s / 127.0f : s; }
 template <int WF> __device__ __forceinline__ float w8_decode(uint32_t byte) {   // byte in bits 0..7
     if constexpr (WF == W8_INT8) return (float)(int)(int8_t)byte;
-    else return fp8_e4m3_to_float(byte & 0xFFu);
+    else return fp8_e4m3_to_float(byte);
 }
 
 // ---------------------------------------------------------------- absmax decode

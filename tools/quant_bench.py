@@ -18,6 +18,6 @@ for dt in (torch.float16, torch.bfloat16):
     algo = 4096 * 4096 * 2 + 4096 * 4096 // 2 + 4096 * 64 * 4
     for name, fn in (("quantize_nf4", lambda: bnb.quantize_nf4(W)), ("quantize_nf4 + double quant", lambda: bnb.quantize_nf4(W, compress_statistics=True)),
                      ("dequantize_nf4", lambda: bnb.dequantize_4bit(p, st)), ("dequantize_nf4 (double-quantised absmax)", lambda: bnb.dequantize_4bit(pc, stc)),
-                     ("quantize_rowwise", lambda: bnb.quantize_rowwise(W))):
+                     ("quantize_rowwise", lambda: bnb.quantize_rowwise(W)), ("quantize_fp8_e4m3", lambda: bnb.quantize_fp8_e4m3(W))):
         us = t(fn)
         print(f"{dt} {name}: {us:.1f} us  ({algo / us / 1e3:.0f} GB/s of 42.99 MB)", flush=True)
