@@ -244,7 +244,8 @@ int mbnb_embedding_8bit(const int64_t *indices, int64_t n_indices, const int8_t 
 
 int64_t mbnb_outlier_linear_workspace_bytes(int64_t M, int64_t K) {
     if (M < 0 || K < 0) return 0;
-    return ((M * K + 255) & ~(int64_t)255) + ((4 * M + 255) & ~(int64_t)255);   // int8 activations + their row scales
+    // int8 activations + their row scales + the compact [M, 16] outlier activations (16-bit)
+    return ((M * K + 255) & ~(int64_t)255) + ((4 * M + 255) & ~(int64_t)255) + ((32 * M + 255) & ~(int64_t)255);
 }
 
 int mbnb_outlier_linear(const void *X, int dtype, int64_t M, int64_t K, const int8_t *W, const float *W_scales, int64_t N,

@@ -160,10 +160,23 @@ __global__ __launch_bounds__(256, 2) void k_gemm_i8(const int8_t *__restrict__ A
 // with BOTH operands arriving by LDS-DMA (no decode): 8 x 1 KiB pieces per wave and k-step, issued one
 // per MFMA right after the barrier that frees the stage; one barrier per k-step between MFMA groups 2
 // and 3, next group's fragments read before the current group's MFMAs.  Requires K % 128 == 0.
+// Optional second term of the epilogue (OutlierAwareLinear.forward, nn/outlier_aware.py:141-143, :110-111):
+//   out = RNE(RNE(RNE(acc * sA/127 * sB/127) + RNE(X[:, oidx] . ow^T)) + bias)
+// x == nullptr: no outlier term; bias == nullptr: no bias; both null: the plain matmul_int8 epilogue.
+struct OutlierEpilogue {
+    const void *x;        // [M, 16] outlier activations (compact, zero padded) in the output dtype (16-bit)
+    int64_t ldx;          // = 16
+    const int64_t *oidx;  // [n_out]
+    int64_t n_out;
+    const void *ow;       // [N, n_out] outlier weights in the output dtype
+    const void *bias;     // [N] or nullptr
+};
+
 template <typename OutT>
 __global__ __launch_bounds__(512, 2) void k_gemm_i8_256(const int8_t *__restrict__ A, const int8_t *__restrict__ Bt,
                                                         const float *__restrict__ sA, const float *__restrict__ sB,
-                                                        OutT *__restrict__ out, int64_t M, int64_t N, int64_t K) {
+                                                        OutT *__restrict__ out, int64_t M, int64_t N, int64_t K,
+                                                        OutlierEpilogue ep) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -280,26 +293,77 @@ __global__ __launch_bounds__(512, 2) void k_gemm_i8_256(const int8_t *__restrict
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
+    const bool with_outliers = ep.x != nullptr && ep.n_out > 0;   // the dispatcher sends n_out <= 16 only
+    const OutT *bias = static_cast<const OutT *>(ep.bias);
+    // outlier operands of this wave, fetched once: 4 weight fragments (rows n, 8 consecutive outliers per lane half: one
+    // 16-byte load when n_out == 16) and 2 activation fragments (rows m, 8 gathered columns)
+    u32x4 wfr[4], xfr[2];
+    if constexpr (sizeof(OutT) == 2) {
+        if (with_outliers) {
+            const OutT *xx = static_cast<const OutT *>(ep.x);
+            const OutT *ow = static_cast<const OutT *>(ep.ow);
+            const bool vec = ep.n_out == 16 && ((reinterpret_cast<uintptr_t>(ow) & 15) == 0);
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+            for (int i = 0; i < 4; i++) {
+                int64_t nrow = n0 + wn * 128 + i * 32 + fr;
+                nrow = nrow < N ? nrow : N - 1;
+                if (vec) {
+                    wfr[i] = *reinterpret_cast<const u32x4 *>(ow + nrow * 16 + 8 * fh);
+                } else {
+                    __attribute__((aligned(16))) OutT t[8];
+#pragma unroll
+                    for (int e = 0; e < 8; e++) t[e] = (8 * fh + e < ep.n_out) ? ow[nrow * ep.n_out + 8 * fh + e] : from_f32<OutT>(0.0f);
+                    wfr[i] = *reinterpret_cast<const u32x4 *>(t);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; j++) {   // ep.x: compact [M, 16] outlier activations written by the quantize kernel
+                int64_t mrow = m0 + wm * 64 + j * 32 + fr;
+                mrow = mrow < M ? mrow : M - 1;
+                xfr[j] = *reinterpret_cast<const u32x4 *>(xx + mrow * 16 + 8 * fh);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        f32x16 o[2];
 #pragma unroll
         for (int j = 0; j < 2; j++) {
-            const int64_t m = m0 + wm * 64 + j * 32 + fr;
-            if (m >= M) continue;
-            const float sa = sA[m] / 127.0f;
 #pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const int64_t n = n0 + wn * 128 + i * 32 + 8 * g + 4 * fh;
-                if (n >= N) continue;
+            for (int e = 0; e < 16; e++) o[j][e] = 0.0f;
+            if constexpr (sizeof(OutT) == 2) {
+                using Fr = typename Mfma<OutT>::frag;
+                if (with_outliers) o[j] = Mfma<OutT>::run(__builtin_bit_cast(Fr, wfr[i]), __builtin_bit_cast(Fr, xfr[j]), o[j]);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const int64_t n = n0 + wn * 128 + i * 32 + 8 * g + 4 * fh;
+            if (n >= N) continue;
+            float sb[4], bv[4];   // column scales and bias of the 4 outputs: once per (i, g), shared by both row tiles
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                sb[e] = (n + e < N) ? sB[n + e] / 127.0f : 0.0f;
+                bv[e] = (bias != nullptr && n + e < N) ? to_f32(bias[n + e]) : 0.0f;
+            }
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int64_t m = m0 + wm * 64 + j * 32 + fr;
+                if (m >= M) continue;
+                const float sa = sA[m] / 127.0f;
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
-                    const float sb = (n + e < N) ? sB[n + e] / 127.0f : 0.0f;
-                    v[e] = (float)acc[i][j][4 * g + e] * sa * sb;
+                    v[e] = (float)acc[i][j][4 * g + e] * sa * sb[e];
+                    if constexpr (sizeof(OutT) == 2) {
+                        if (with_outliers) v[e] = to_f32(from_f32<OutT>(to_f32(from_f32<OutT>(v[e])) + to_f32(from_f32<OutT>(o[j][4 * g + e]))));
+                        if (bias != nullptr) v[e] = to_f32(from_f32<OutT>(to_f32(from_f32<OutT>(v[e])) + bv[e]));
+                    }
                 }
                 store4(out + m * N + n, v, n, N);
             }
         }
+    }
 }
 
 // odd K (not a multiple of 16) or unaligned pointers: one wave per output element row
@@ -328,8 +392,12 @@ __global__ __launch_bounds__(256) void k_matmul_i8_generic_nt(const int8_t *__re
     out[i] = from_f32<OutT>((float)acc * (sA[m] / 127.0f) * (sB[n] / 127.0f));
 }
 
+// `ep` (may be nullptr): outlier / bias epilogue.  It is applied only by the 256 x 256 kernel with a 16-bit output;
+// *ep_done tells the caller whether it was (otherwise the caller runs k_outlier_add afterwards).
 int matmul_int8_nt_dispatch(const int8_t *A, const int8_t *Bt, const float *sA, const float *sB, int64_t M, int64_t N,
-                            int64_t K, int out_dtype, void *out, hipStream_t st) {
+                            int64_t K, int out_dtype, void *out, hipStream_t st, const OutlierEpilogue *ep = nullptr,
+                            bool *ep_done = nullptr) {
+    if (ep_done) *ep_done = false;
     const bool fast = (K % 16 == 0) && ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(Bt)) & 15) == 0;
     if (!fast) {
         const unsigned grid = (unsigned)((M * N + 255) / 256);
@@ -344,6 +412,11 @@ int matmul_int8_nt_dispatch(const int8_t *A, const int8_t *Bt, const float *sA, 
     if ((K % 128 == 0) && ((M + 255) / 256) * ((N + 255) / 256) >= 96) {
         const int64_t tiles256 = ((M + 255) / 256) * ((N + 255) / 256);
         constexpr int lds256 = 4 * P_IMG;
+        OutlierEpilogue epv{nullptr, 0, nullptr, 0, nullptr, nullptr};
+        if (ep != nullptr && out_dtype != MBNB_F32 && ep->n_out <= 16) {
+            epv = *ep;
+            if (ep_done) *ep_done = true;
+        }
 #define MBNB_I8_256(OT)                                                                                              \
     do {                                                                                                             \
         auto kern = k_gemm_i8_256<OT>;                                                                               \
@@ -353,7 +426,7 @@ int matmul_int8_nt_dispatch(const int8_t *A, const int8_t *Bt, const float *sA, 
             set_error("matmul_int8: hipFuncSetAttribute failed: %s", hipGetErrorString(e));                          \
             return (int)e;                                                                                           \
         }                                                                                                            \
-        hipLaunchKernelGGL(kern, dim3((unsigned)tiles256), dim3(512), lds256, st, A, Bt, sA, sB, static_cast<OT *>(out), M, N, K); \
+        hipLaunchKernelGGL(kern, dim3((unsigned)tiles256), dim3(512), lds256, st, A, Bt, sA, sB, static_cast<OT *>(out), M, N, K, epv); \
     } while (0)
         switch (out_dtype) {
             case MBNB_F16: MBNB_I8_256(f16_t); break;

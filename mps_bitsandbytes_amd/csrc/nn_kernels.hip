@@ -14,8 +14,16 @@ namespace mbnb {
 int check_launch(const char *what);
 void set_error(const char *fmt, ...);
 void set_kernel_name(const char *name);
+struct OutlierEpilogue {   // int8_kernels.hip: optional outlier / bias term of the 256 x 256 int8 kernel's epilogue
+    const void *x;
+    int64_t ldx;
+    const int64_t *oidx;
+    int64_t n_out;
+    const void *ow;
+    const void *bias;
+};
 int matmul_int8_nt_dispatch(const int8_t *A, const int8_t *Bt, const float *sA, const float *sB, int64_t M, int64_t N,
-                            int64_t K, int out_dtype, void *out, hipStream_t st);
+                            int64_t K, int out_dtype, void *out, hipStream_t st, const OutlierEpilogue *ep, bool *ep_done);
 
 // ------------------------------------------------------------------------------------ embeddings
 // One workgroup per looked-up row.  A thread decodes 4 packed bytes (8 values) per trip: u32 load, table
@@ -154,7 +162,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_quantize_rowwise_masked(const T *__restrict__ A, int64_t rows, int64_t cols,
                                                                 const int64_t *__restrict__ oidx, int64_t n_out,
                                                                 int8_t *__restrict__ out, float *__restrict__ scales,
-                                                                bool vec_ok) {
+                                                                T *__restrict__ xo, bool vec_ok) {
     // column mask of the outlier set, rebuilt per workgroup in LDS (cols bytes, rounded up to 8): cheaper than a
     // global mask + two extra launches for the handful of outlier columns of a layer
     extern __shared__ __attribute__((aligned(8))) uint8_t mask[];
@@ -197,6 +205,9 @@ __global__ __launch_bounds__(256) void k_quantize_rowwise_masked(const T *__rest
     __syncthreads();
     am = fmaxf(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])), 1e-8f);
     if (threadIdx.x == 0) scales[r] = am;
+    // the row's outlier activations, compact and padded to 16: the GEMM epilogue reads them as one 16-byte fragment
+    if (xo != nullptr && threadIdx.x < 16)
+        xo[r * 16 + threadIdx.x] = (threadIdx.x < n_out) ? row[oidx[threadIdx.x]] : from_f32<T>(0.0f);
     const float s = rscale127(am);
     int8_t *orow = out + r * cols;
     for (int64_t g = threadIdx.x; g < nvec; g += 256) {
@@ -319,11 +330,13 @@ template <typename T>
 static int launch_outlier_linear(const void *X, int64_t M, int64_t K, const int8_t *W, const float *w_scales, int64_t N,
                                  const int64_t *oidx, int64_t n_out, const void *ow, const void *bias, void *out,
                                  void *workspace, int dtype, hipStream_t st) {
-    // workspace: [x_q int8 M*K | pad to 256][x_scales f32 M]
+    // workspace: [x_q int8 M*K | pad to 256][x_scales f32 M | pad to 256][outlier activations M x 16 (16-bit types)]
     char *ws = static_cast<char *>(workspace);
     int8_t *xq = reinterpret_cast<int8_t *>(ws);
     const int64_t off_s = (M * K + 255) & ~(int64_t)255;
     float *xs = reinterpret_cast<float *>(ws + off_s);
+    const int64_t off_x = off_s + ((4 * M + 255) & ~(int64_t)255);
+    T *xo = (n_out > 0 && n_out <= 16 && sizeof(T) == 2) ? reinterpret_cast<T *>(ws + off_x) : nullptr;
     const size_t mask_lds = (size_t)((K + 7) & ~(int64_t)7);
     if (mask_lds > 65536) {
         set_error("outlier_linear: in_features %lld too large for the LDS column mask", (long long)K);
@@ -331,12 +344,16 @@ static int launch_outlier_linear(const void *X, int64_t M, int64_t K, const int8
     }
     const bool vec_ok = (K % 8 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
     hipLaunchKernelGGL(k_quantize_rowwise_masked<T>, dim3((unsigned)M), dim3(256), mask_lds, st, static_cast<const T *>(X), M, K,
-                       oidx, n_out, xq, xs, vec_ok);
+                       oidx, n_out, xq, xs, xo, vec_ok);
     int rc = check_launch("outlier_linear(quantize)");
     if (rc) return rc;
-    rc = matmul_int8_nt_dispatch(xq, W, xs, w_scales, M, N, K, dtype, out, st);
+    // the 256 x 256 kernel folds the outlier columns and the bias into its epilogue (one MFMA per tile and 16 outliers);
+    // the other int8 kernels leave them to k_outlier_add
+    const OutlierEpilogue ep{xo, 16, oidx, n_out, ow, bias};   // x: the compact [M, 16] outlier activations
+    bool fused = false;
+    rc = matmul_int8_nt_dispatch(xq, W, xs, w_scales, M, N, K, dtype, out, st, ((n_out == 0 || xo != nullptr) && (n_out > 0 || bias)) ? &ep : nullptr, &fused);
     if (rc) return rc;
-    if (n_out > 0 || bias) {
+    if (!fused && (n_out > 0 || bias)) {
         dim3 grid((unsigned)((N + 511) / 512), (unsigned)((M + 15) / 16));
         const bool vec_out = (N % 2 == 0) && ((reinterpret_cast<uintptr_t>(out) & 7) == 0);
         const bool ow_vec = (n_out % 8 == 0) && ((reinterpret_cast<uintptr_t>(ow) & 15) == 0);

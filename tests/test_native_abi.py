@@ -65,8 +65,8 @@ def test_workspace_size_functions_are_pure_host_code():
     assert lib.mbnb_matmul_4bit_workspace_bytes(1024, 4096, 4096) == 2 * 256 * 65536
     assert lib.mbnb_matmul_4bit_workspace_bytes(128, 4096, 72) == 0               # K % 64 != 0
     assert lib.mbnb_matmul_4bit_workspace_bytes(0, 4096, 4096) == 0
-    assert lib.mbnb_outlier_linear_workspace_bytes(4096, 4096) == 4096 * 4096 + 4 * 4096
-    assert lib.mbnb_outlier_linear_workspace_bytes(3, 5) == 256 + 256
+    assert lib.mbnb_outlier_linear_workspace_bytes(4096, 4096) == 4096 * 4096 + 4 * 4096 + 32 * 4096
+    assert lib.mbnb_outlier_linear_workspace_bytes(3, 5) == 256 + 256 + 256
 
 
 def test_product_has_no_cpu_path_and_never_imports_the_oracle():
