@@ -148,6 +148,21 @@ template <int WF> __device__ __forceinline__ float w8_decode(uint32_t byte) {   
     if constexpr (WF == W8_INT8) return (float)(int)(int8_t)byte;
     else return fp8_e4m3_to_float(byte);
 }
+// byte `sel` (0..3, a constant after unrolling) of `word`.  FP8: gfx950's v_cvt_f32_fp8 is the OCP E4M3 conversion, which
+// is exactly the reference's decoder (bias 7, subnormals, NaN at 0x7F / 0xFF) -- one instruction including the byte
+// select; fp8_e4m3_to_float above is the same function in portable arithmetic (dequantize kernel, all-bytes test).
+template <int WF> __device__ __forceinline__ float w8_decode_sel(uint32_t word, int sel) {
+    if constexpr (WF == W8_INT8) {
+        return (float)(int)(int8_t)(word >> (8 * sel));
+    } else {
+        switch (sel) {
+            case 0: return __builtin_amdgcn_cvt_f32_fp8((int)word, 0);
+            case 1: return __builtin_amdgcn_cvt_f32_fp8((int)word, 1);
+            case 2: return __builtin_amdgcn_cvt_f32_fp8((int)word, 2);
+            default: return __builtin_amdgcn_cvt_f32_fp8((int)word, 3);
+        }
+    }
+}
 
 // ---------------------------------------------------------------- absmax decode
 struct AbsmaxView {

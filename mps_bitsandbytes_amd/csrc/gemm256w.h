@@ -94,8 +94,8 @@ __global__ __launch_bounds__(512, 2) void k_gemm256w(const T *__restrict__ X, ty
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const uint32_t w = r[d >> 1][2 * (d & 1) + (j >> 1)];
-            const float q0 = w8_decode<WF>(w >> (16 * (j & 1)));
-            const float q1 = w8_decode<WF>(w >> (16 * (j & 1) + 8));
+            const float q0 = w8_decode_sel<WF>(w, 2 * (j & 1));
+            const float q1 = w8_decode_sel<WF>(w, 2 * (j & 1) + 1);
             o[j] = pack2<T>(q0 * sc, q1 * sc);
         }
         *reinterpret_cast<u32x4 *>(smem + stage * P_IMG + bw_off[d]) = o;

@@ -140,8 +140,8 @@ template <typename T, int WF = W8_INT8> struct I8Producer {
             for (int j = 0; j < 4; j++) {
                 // 8 int8 per output chunk: dwords 2*(d&1), 2*(d&1)+1 of half d>>1
                 const uint32_t w = r.w[d >> 1][2 * (d & 1) + (j >> 1)];
-                const float q0 = w8_decode<WF>(w >> (16 * (j & 1)));
-                const float q1 = w8_decode<WF>(w >> (16 * (j & 1) + 8));
+                const float q0 = w8_decode_sel<WF>(w, 2 * (j & 1));
+                const float q1 = w8_decode_sel<WF>(w, 2 * (j & 1) + 1);
                 o[j] = pack2<T>((float)q0 * r.s, (float)q1 * r.s);
             }
             *reinterpret_cast<u32x4 *>(tile + swz_off(row, chunk0 + d)) = o;

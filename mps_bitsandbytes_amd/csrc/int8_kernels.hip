@@ -556,8 +556,8 @@ __global__ __launch_bounds__(1024) void k_skinny8(const T *__restrict__ X, const
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const uint32_t wd = w[g >> 1][2 * (g & 1) + (j >> 1)];
-                const float q0 = w8_decode<WF>(wd >> (16 * (j & 1)));
-                const float q1 = w8_decode<WF>(wd >> (16 * (j & 1) + 8));
+                const float q0 = w8_decode_sel<WF>(wd, 2 * (j & 1));
+                const float q1 = w8_decode_sel<WF>(wd, 2 * (j & 1) + 1);
                 fr[j] = pack2<T>(q0 * sc, q1 * sc);
             }
             const auto af = __builtin_bit_cast(typename Mfma16<T>::frag, fr);

@@ -216,3 +216,24 @@ def test_linear_fp8_kernels_vs_oracle(M, N, K, dt, kern):
     rows = torch.arange(0, M, max(1, M // 64))[:64]
     ref = oracle.linear_fp8(x[rows], q, s, b)
     assert rel_fro(y.cpu()[rows], ref) <= (2e-4 if dt == torch.float16 else 2e-3)
+
+
+def test_fp8_hardware_decoder_matches_reference_decoder_for_every_byte():
+    """The GEMM producers decode FP8 with gfx950's v_cvt_f32_fp8; the dequantize kernel uses the portable restatement of
+    the reference's decoder.  One-hot activations pull every byte value (subnormals included) through the GEMM path."""
+    codes = torch.arange(256, dtype=torch.int64)
+    codes[0x7F], codes[0xFF] = 0, 0x80                       # NaN bytes: checked separately below
+    W = codes.to(torch.uint8).reshape(2, 128).to(DEV)
+    scales = torch.tensor([1.0, 1.0], device=DEV)
+    want = bnb.dequantize_fp8_e4m3(W, scales, torch.float32)                      # [2, 128], portable decoder
+    for half in range(2):
+        x = torch.zeros(64, 128, dtype=torch.float16, device=DEV)
+        x[torch.arange(64), 64 * half + torch.arange(64)] = 1.0
+        y = bnb.matmul_fp8_e4m3(x, W, scales, None, torch.float16)               # [64, 2]
+        assert _native.last_kernel() == "fp8a16_skinny"
+        ref = want[:, 64 * half:64 * half + 64].t().to(torch.float16)
+        assert torch.equal(y.float(), ref.float()), half                          # -0.0 == +0.0
+    Wn = torch.full((1, 128), 0x38, dtype=torch.uint8, device=DEV)                # 1.0 everywhere ...
+    Wn[0, 5] = 0x7F                                                               # ... and one NaN byte
+    y = bnb.matmul_fp8_e4m3(torch.ones(2, 128, dtype=torch.float16, device=DEV), Wn, torch.ones(1, device=DEV), None, torch.float16)
+    assert bool(torch.isnan(y).all())
