@@ -308,42 +308,77 @@ __device__ __forceinline__ void epilogue_staged(const f32x16 (&acc)[4][NJ], char
     static_assert(sizeof(OutT) == 2, "staged epilogue is for 16-bit outputs");
     constexpr int ROWB = 264;  // 256 B of outputs + 8 B pad: ds_write_b64 of 32 rows -> 2-way conflicts at most
     const int fr = lane & 31, fh = lane >> 5;
+    // phase 1, in two straight-line versions (with / without bias: a per-element test of the pointer is a taken branch
+    // per accumulator).  The four bias values of a lane's column group depend on (i, g) only: loaded once, index clamped
+    // instead of guarded (the out-of-range columns are never stored).
+    auto stage_tiles = [&](auto with_bias) {
+        constexpr bool WB = decltype(with_bias)::value;
 #pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++)
+        for (int i = 0; i < 4; i++)
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 const int nl = i * 32 + 8 * g + 4 * fh;  // local column of the first of 4 outputs
-                float v[4];
+                float bv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                if constexpr (WB) {
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    float s = acc[i][J0 + j][4 * g + e];
-                    const int64_t n = n_base + nl + e;
-                    if (bias != nullptr && n < N) s += to_f32(bias[n]);
-                    v[e] = to_f32(from_f32<T>(s));  // one rounding to the compute dtype
+                    for (int e = 0; e < 4; e++) {
+                        const int64_t n = n_base + nl + e;
+                        bv[e] = to_f32(bias[n < N ? n : N - 1]);
+                    }
                 }
-                *reinterpret_cast<u32x2 *>(wave_lds + (j * 32 + fr) * ROWB + nl * 2) =
-                    u32x2{pack2<OutT>(v[0], v[1]), pack2<OutT>(v[2], v[3])};
-                if constexpr (NJ > 2) __builtin_amdgcn_sched_barrier(0);   // 256-accumulator kernels: bound the live range of the reads
+                if constexpr (NJ > 2) __builtin_amdgcn_sched_barrier(0);   // bound the live range of the accumulator reads
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        float s;
+                        if constexpr (NJ > 2) {
+                            // 256-accumulator kernels: pull each value out of its AGPR where it is used (otherwise the
+                            // allocator copies all 256 to VGPRs at the loop exit and spills what does not fit)
+                            asm("v_accvgpr_read_b32 %0, %1" : "=v"(s) : "a"(acc[i][J0 + j][4 * g + e]));
+                        } else {
+                            s = acc[i][J0 + j][4 * g + e];
+                        }
+                        if constexpr (WB) s += bv[e];
+                        v[e] = to_f32(from_f32<T>(s));  // one rounding to the compute dtype
+                    }
+                    *reinterpret_cast<u32x2 *>(wave_lds + (j * 32 + fr) * ROWB + nl * 2) =
+                        u32x2{pack2<OutT>(v[0], v[1]), pack2<OutT>(v[2], v[3])};
+                }
             }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private tile: no barrier needed
+    };
+    if (bias != nullptr) stage_tiles(std::true_type{});
+    else stage_tiles(std::false_type{});
+    // wave-private tile: no barrier, and no wait either -- one wave's LDS instructions execute in issue order, so the
+    // reads below see the writes above (the compiler waits for each read's data before the store that uses it)
     const bool vec_ok = (N % 8 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+    // all staging reads first (unconditional, pipelined), then the guarded stores: with the bounds test in front of
+    // each read every iteration would expose one LDS round trip
+    const int ch = lane & 15;  // 4 rows x 16 chunks of 16 B per instruction
+    u32x4 piece[16];
 #pragma unroll
     for (int p = 0; p < 16; p++) {
-        const int row = p * 4 + (lane >> 4), ch = lane & 15;  // 4 rows x 16 chunks of 16 B per instruction
-        const int64_t m = m_base + row, n = n_base + ch * 8;
-        if (m >= M || n >= N) continue;
-        const char *src = wave_lds + row * ROWB + ch * 16;
+        const char *src = wave_lds + (p * 4 + (lane >> 4)) * ROWB + ch * 16;
         const u32x2 lo = *reinterpret_cast<const u32x2 *>(src), hi = *reinterpret_cast<const u32x2 *>(src + 8);
-        OutT *dst = out + m * N + n;
-        if (vec_ok && n + 8 <= N) {
-            *reinterpret_cast<u32x4 *>(dst) = u32x4{lo[0], lo[1], hi[0], hi[1]};
-        } else {
-            const uint32_t w[4] = {lo[0], lo[1], hi[0], hi[1]};
+        piece[p] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+    }
+    const int64_t n = n_base + ch * 8;
+    if (n >= N) return;
+    if (vec_ok && n + 8 <= N) {
+#pragma unroll
+        for (int p = 0; p < 16; p++) {
+            const int64_t m = m_base + p * 4 + (lane >> 4);
+            if (m < M) *reinterpret_cast<u32x4 *>(out + m * N + n) = piece[p];
+        }
+    } else {
+#pragma unroll
+        for (int p = 0; p < 16; p++) {
+            const int64_t m = m_base + p * 4 + (lane >> 4);
+            if (m >= M) continue;
 #pragma unroll
             for (int e = 0; e < 8; e++)
-                if (n + e < N) reinterpret_cast<uint16_t *>(dst)[e] = (uint16_t)(w[e >> 1] >> (16 * (e & 1)));
+                if (n + e < N) reinterpret_cast<uint16_t *>(out + m * N + n)[e] = (uint16_t)(piece[p][e >> 1] >> (16 * (e & 1)));
         }
     }
 }

@@ -22,10 +22,18 @@
 // pinned address registers.
 #pragma once
 #include "gemm256.h"
+#include <utility>
 
 namespace mbnb {
 
-template <typename T, bool NESTED>
+template <int... I, class F> __device__ __forceinline__ void q4w_static_for_impl(std::integer_sequence<int, I...>, F &&f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F> __device__ __forceinline__ void q4w_static_for(F &&f) {
+    q4w_static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F &&>(f));
+}
+
+template <typename T, bool NESTED, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void k_gemm256q(const T *__restrict__ X, typename Q4ProducerRT<T, NESTED>::Params wp,
                                                      const T *__restrict__ bias, void *__restrict__ out_v, int out_dtype,
                                                      int64_t M, int64_t N, int64_t K) {
@@ -79,18 +87,19 @@ __global__ __launch_bounds__(256, 1) void k_gemm256q(const T *__restrict__ X, ty
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         const int row = 8 * (wave * 8 + i) + (lane >> 3);
-        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        const int c = (ABL & 16) ? (lane & 7) : ((lane & 7) ^ ((row >> 1) & 7));
         int64_t m = m0 + row;
         m = m < M ? m : M - 1;
         a_off[i] = (uint32_t)((m * K + 8 * c) * (int64_t)sizeof(T));
     }
     auto issue_a = [&](int stage, int64_t k0, int first, int count) {
+        if constexpr (ABL & 2) return;
         const char *xb = reinterpret_cast<const char *>(X) + k0 * (int64_t)sizeof(T);   // uniform
 #pragma unroll
         for (int i = first; i < first + count; i++) {
             auto g = (const __attribute__((address_space(1))) void *)(xb + a_off[i]);
             auto l = (__attribute__((address_space(3))) void *)(smem + P_A + stage * P_IMG + (wave * 8 + i) * 1024);
-            __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
+            lds_dma<16>((const void *)g, (uint32_t)(uintptr_t)l);
         }
     };
 
@@ -112,7 +121,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm256q(const T *__restrict__ X, ty
         for (int p = 0; p < 2; p++) {
             auto g = (const __attribute__((address_space(1))) void *)(pb + p_off[p]);
             auto l = (__attribute__((address_space(3))) void *)(smem + P_RAW + rs * RAWQ + wave * 2048 + p * 1024);
-            __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
+            lds_dma<16>((const void *)g, (uint32_t)(uintptr_t)l);
         }
     };
     // absmax of four consecutive k-steps (block b = tiles 4b .. 4b+3 -> slot b & 1): lane l fetches row 64w + l
@@ -125,15 +134,15 @@ __global__ __launch_bounds__(256, 1) void k_gemm256q(const T *__restrict__ X, ty
         if constexpr (!NESTED) {
             auto g = (const __attribute__((address_space(1))) void *)(reinterpret_cast<const char *>(wp.am.f32 + 4 * b) + am4_idx * 4u);
             auto l = (__attribute__((address_space(3))) void *)(smem + P_AM4 + (int)(blk & 1) * AM4_BLK + wave * 1024);
-            __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
+            lds_dma<16>((const void *)g, (uint32_t)(uintptr_t)l);
         } else {
             const int64_t ai = (int64_t)am4_idx + 4 * b;
             auto g = (const __attribute__((address_space(1))) void *)(wp.am.i8 + ai);
             auto l = (__attribute__((address_space(3))) void *)(smem + P_AM4 + (int)(blk & 1) * AM4_BLK + wave * 256);
-            __builtin_amdgcn_global_load_lds(g, l, 4, 0, 0);
+            lds_dma<4>((const void *)g, (uint32_t)(uintptr_t)l);
             auto g2 = (const __attribute__((address_space(1))) void *)(wp.am.am2 + (ai >> wp.bs2_shift));
             auto l2 = (__attribute__((address_space(3))) void *)(smem + P_AM4 + (int)(blk & 1) * AM4_BLK + 1024 + wave * 256);
-            __builtin_amdgcn_global_load_lds(g2, l2, 4, 0, 0);
+            lds_dma<4>((const void *)g2, (uint32_t)(uintptr_t)l2);
         }
     };
     const int64_t nk = K >> 6;
@@ -172,6 +181,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm256q(const T *__restrict__ X, ty
     // quarter Q = 4 * pass + d: lookups (4 x ds_read_b64 from the byte table) and products
     // (code * absmax in f32 -> RNE 16 bit: the reference's dequantize_4bit bits) -> ds_write_b128
     auto lookup_q = [&](uint32_t w, float (&L)[8]) {
+        if constexpr (ABL & 1) return;
         const char *lut2 = reinterpret_cast<const char *>(s_lut2);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -207,19 +217,9 @@ __global__ __launch_bounds__(256, 1) void k_gemm256q(const T *__restrict__ X, ty
 #pragma unroll
         for (int j = 0; j < 4; j++) xf[j] = *reinterpret_cast<const Frag *>(smem + fx[s] + stage * P_IMG + j * 32 * ROW_BYTES);
     };
+    // accumulators: never zero-filled -- the very first MFMA group takes a literal-zero C operand instead, so no
+    // 256 zeros have to exist in VGPRs on the way into the loop (that peak is what made the allocator spill)
     f32x16 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-#pragma unroll
-            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
-    auto mfma_group = [&](const Frag (&wf)[4], const Frag (&xf)[4]) {
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) acc[i][j] = Mfma<T>::run(wf[i], xf[j], acc[i][j]);
-    };
 
     using P0 = std::integral_constant<int, 0>;
     using P1 = std::integral_constant<int, 1>;
@@ -240,7 +240,6 @@ __global__ __launch_bounds__(256, 1) void k_gemm256q(const T *__restrict__ X, ty
             float Lt[8];
             lookup_q(rw[0][p][d], Lt);
             finish_q(Lt, ram[0][p], p, d, 0);
-            __builtin_amdgcn_sched_barrier(0);   // one quarter at a time: keeps the prologue's register peak low
         }
     load_raw(P1{}, 1);
     lookup_q(rw[1][0][0], L[0]);
@@ -253,59 +252,121 @@ __global__ __launch_bounds__(256, 1) void k_gemm256q(const T *__restrict__ X, ty
     Frag wfA[4], xfA[4], wfB[4], xfB[4];
     read_frags(0, 0, wfA, xfA);
 
-    auto kstep = [&](auto cc, int64_t j) {
+    // ---- slot-pinned k-step.  One wave per SIMD means a run of non-MFMA instructions is never hidden by another
+    // wave's MFMAs, and a use placed right behind its LDS read stalls the MFMA stream: so every group is written as
+    // 16 slots (one MFMA + its fillers, fenced by sched_barrier), with every LDS result consumed >= 12 slots after
+    // its read was issued:
+    //   R(s) fragment reads of sub-step s (2 per slot)   L(q) lookups of quarter q   Fa/Fb(q) products + image write
+    //   group 0: R(1) 0-3 | L2 L3 L4 @4-6 | F0 @8,9  F1 @10,11 | A-DMA @12,13
+    //   group 1: R(2) 0-3 | L5 L6 L7 @4-6 | F2 @7,8  F3 @9,10  F4 @11,12 | A-DMA @13,14
+    //   group 2: R(3) 0-3 | F5 @4,5  F6 @6,7  F7 @8,9 | raw DMA @10, absmax DMA @11 | wait + barrier
+    //   group 3: R'(0) 0-3 (next stage) | raw -> registers @4 | A-DMA @5-8 | L0 @10  L1 @12
+    auto read_frag_pair = [&](int stage, int s, int idx, Frag (&wf)[4], Frag (&xf)[4]) {
+        if constexpr (ABL & 4) return;
+        wf[idx] = *reinterpret_cast<const Frag *>(smem + fw[s] + stage * P_IMG + idx * 32 * ROW_BYTES);
+        xf[idx] = *reinterpret_cast<const Frag *>(smem + fx[s] + stage * P_IMG + idx * 32 * ROW_BYTES);
+    };
+    u32x4 fo;   // image row piece between the two halves of a finish
+    auto finish_a = [&](const float (&Lq)[8], float am) {
+        if constexpr (ABL & 1) return;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            float p0, p1;
+            asm("v_mul_f32 %0, %1, %2" : "=v"(p0) : "v"(Lq[2 * j]), "v"(am));
+            asm("v_mul_f32 %0, %1, %2" : "=v"(p1) : "v"(Lq[2 * j + 1]), "v"(am));
+            fo[j] = pack2<T>(p0, p1);
+        }
+    };
+    auto finish_b = [&](const float (&Lq)[8], float am, int p, int d, int stage) {
+        if constexpr (ABL & 1) return;
+#pragma unroll
+        for (int j = 2; j < 4; j++) {
+            float p0, p1;
+            asm("v_mul_f32 %0, %1, %2" : "=v"(p0) : "v"(Lq[2 * j]), "v"(am));
+            asm("v_mul_f32 %0, %1, %2" : "=v"(p1) : "v"(Lq[2 * j + 1]), "v"(am));
+            fo[j] = pack2<T>(p0, p1);
+        }
+        *reinterpret_cast<u32x4 *>(smem + stage * P_IMG + bw_off[p][d]) = fo;
+    };
+    auto group = [&](const Frag (&wf)[4], const Frag (&xf)[4], auto first, auto &&fill) {
+        q4w_static_for<16>([&](auto rr) {
+            constexpr int r = decltype(rr)::value, i = r >> 2, jj = r & 3;
+            if constexpr (decltype(first)::value) {
+                const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                acc[i][jj] = Mfma<T>::run(wf[i], xf[jj], zero);
+            } else if constexpr (ABL & 8) {
+            } else {
+                acc[i][jj] = Mfma<T>::run(wf[i], xf[jj], acc[i][jj]);
+            }
+            fill(rr);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+    auto kstep = [&](auto cc, auto first, int64_t j) {
         constexpr int C = decltype(cc)::value, Nn = C ^ 1;
+        constexpr bool FIRST = decltype(first)::value;
         using PC = std::integral_constant<int, C>;
-        // group 0
-        read_frags(C, 1, wfB, xfB);
-        mfma_group(wfA, xfA);
-        finish_q(L[0], ram[Nn][0], 0, 0, Nn);
-        finish_q(L[1], ram[Nn][0], 0, 1, Nn);
-        lookup_q(rw[Nn][0][2], L[2]);
-        lookup_q(rw[Nn][0][3], L[3]);
-        lookup_q(rw[Nn][1][0], L[4]);
-        if (j > 0) issue_a(Nn, kclamp(j + 1), 4, 2);
-        __builtin_amdgcn_sched_barrier(0);
-        // group 1
-        read_frags(C, 2, wfA, xfA);
-        mfma_group(wfB, xfB);
-        finish_q(L[2], ram[Nn][0], 0, 2, Nn);
-        finish_q(L[3], ram[Nn][0], 0, 3, Nn);
-        finish_q(L[4], ram[Nn][1], 1, 0, Nn);
-        lookup_q(rw[Nn][1][1], L[5]);
-        lookup_q(rw[Nn][1][2], L[6]);
-        lookup_q(rw[Nn][1][3], L[7]);
-        if (j > 0) issue_a(Nn, kclamp(j + 1), 6, 2);
-        __builtin_amdgcn_sched_barrier(0);
-        // group 2
-        read_frags(C, 3, wfB, xfB);
-        mfma_group(wfA, xfA);
-        finish_q(L[5], ram[Nn][1], 1, 1, Nn);
-        finish_q(L[6], ram[Nn][1], 1, 2, Nn);
-        finish_q(L[7], ram[Nn][1], 1, 3, Nn);
-        issue_raw(Nn, kclamp(j + 3));
+        const int64_t k1 = kclamp(j + 1), k2 = kclamp(j + 2);
+        group(wfA, xfA, first, [&](auto rr) {
+            constexpr int r = decltype(rr)::value;
+            if constexpr (r < 4) read_frag_pair(C, 1, r, wfB, xfB);
+            if constexpr (r == 4) lookup_q(rw[Nn][0][2], L[2]);
+            if constexpr (r == 5) lookup_q(rw[Nn][0][3], L[3]);
+            if constexpr (r == 6) lookup_q(rw[Nn][1][0], L[4]);
+            if constexpr (r == 8) finish_a(L[0], ram[Nn][0]);
+            if constexpr (r == 9) finish_b(L[0], ram[Nn][0], 0, 0, Nn);
+            if constexpr (r == 10) finish_a(L[1], ram[Nn][0]);
+            if constexpr (r == 11) finish_b(L[1], ram[Nn][0], 0, 1, Nn);
+            if constexpr (!FIRST && (r == 12 || r == 13)) issue_a(Nn, k1, r - 8, 1);
+        });
+        group(wfB, xfB, std::false_type{}, [&](auto rr) {
+            constexpr int r = decltype(rr)::value;
+            if constexpr (r < 4) read_frag_pair(C, 2, r, wfA, xfA);
+            if constexpr (r == 4) lookup_q(rw[Nn][1][1], L[5]);
+            if constexpr (r == 5) lookup_q(rw[Nn][1][2], L[6]);
+            if constexpr (r == 6) lookup_q(rw[Nn][1][3], L[7]);
+            if constexpr (r == 7) finish_a(L[2], ram[Nn][0]);
+            if constexpr (r == 8) finish_b(L[2], ram[Nn][0], 0, 2, Nn);
+            if constexpr (r == 9) finish_a(L[3], ram[Nn][0]);
+            if constexpr (r == 10) finish_b(L[3], ram[Nn][0], 0, 3, Nn);
+            if constexpr (r == 11) finish_a(L[4], ram[Nn][1]);
+            if constexpr (r == 12) finish_b(L[4], ram[Nn][1], 1, 0, Nn);
+            if constexpr (!FIRST && (r == 13 || r == 14)) issue_a(Nn, k1, r - 7, 1);
+        });
         const bool am_now = ((j + 3) & 3) == 0;
-        if (am_now) issue_am4((j + 3) >> 2);
-        __builtin_amdgcn_sched_barrier(0);
+        group(wfA, xfA, std::false_type{}, [&](auto rr) {
+            constexpr int r = decltype(rr)::value;
+            if constexpr (r < 4) read_frag_pair(C, 3, r, wfB, xfB);
+            if constexpr (r == 4) finish_a(L[5], ram[Nn][1]);
+            if constexpr (r == 5) finish_b(L[5], ram[Nn][1], 1, 1, Nn);
+            if constexpr (r == 6) finish_a(L[6], ram[Nn][1]);
+            if constexpr (r == 7) finish_b(L[6], ram[Nn][1], 1, 2, Nn);
+            if constexpr (r == 8) finish_a(L[7], ram[Nn][1]);
+            if constexpr (r == 9) finish_b(L[7], ram[Nn][1], 1, 3, Nn);
+            if constexpr (r == 10) issue_raw(Nn, kclamp(j + 3));
+            if constexpr (r == 11) { if (am_now) issue_am4((j + 3) >> 2); }
+        });
         // everything but what this group just issued has landed: A(j+1), raw(j+2), older absmax blocks
         if (am_now) { if constexpr (NESTED) MBNB_VMCNT(4); else MBNB_VMCNT(3); } else { MBNB_VMCNT(2); }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // own decode writes + fragment reads done
         __builtin_amdgcn_s_barrier();                         // stage Nn complete, stage C free
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        // group 3: first fragments of stage Nn; refill stage C; raw(j+2) -> registers; look up its quarters 0,1
-        read_frags(Nn, 0, wfA, xfA);
-        load_raw(PC{}, j + 2);
-        mfma_group(wfB, xfB);
-        lookup_q(rw[C][0][0], L[0]);
-        lookup_q(rw[C][0][1], L[1]);
-        issue_a(C, kclamp(j + 2), 0, 4);
-        __builtin_amdgcn_sched_barrier(0);
+        group(wfB, xfB, std::false_type{}, [&](auto rr) {
+            constexpr int r = decltype(rr)::value;
+            if constexpr (r < 4) read_frag_pair(Nn, 0, r, wfA, xfA);
+            if constexpr (r == 4) load_raw(PC{}, j + 2);
+            if constexpr (r >= 5 && r <= 8) issue_a(C, k2, r - 5, 1);
+            if constexpr (r == 10) lookup_q(rw[C][0][0], L[0]);
+            if constexpr (r == 12) lookup_q(rw[C][0][1], L[1]);
+        });
     };
-    static_assert(AMN >= 1, "");
-    for (int64_t j = 0; j < nk; j += 2) {
-        kstep(std::integral_constant<int, 0>{}, j);
-        if (j + 1 < nk) kstep(std::integral_constant<int, 1>{}, j + 1);
+    // nk is even and >= 4 (K % 256 == 0); the first pair of k-steps is peeled for the literal-zero accumulate
+    kstep(std::integral_constant<int, 0>{}, std::true_type{}, 0);
+    kstep(std::integral_constant<int, 1>{}, std::false_type{}, 1);
+    for (int64_t j = 2; j < nk; j += 2) {
+        kstep(std::integral_constant<int, 0>{}, std::false_type{}, j);
+        kstep(std::integral_constant<int, 1>{}, std::false_type{}, j + 1);
     }
     MBNB_VMCNT(0);
 
@@ -319,19 +380,23 @@ __global__ __launch_bounds__(256, 1) void k_gemm256q(const T *__restrict__ X, ty
     int tid2 = threadIdx.x;
     asm volatile("" : "+v"(tid2));
     const int lane_e = tid2 & 63;
+#ifndef Q_NOSTAGED
+    if constexpr (ABL & 64) {   // timing only: no epilogue (one conditional store keeps the accumulators alive)
+        if (acc[0][0][0] == 12345.678f && acc[3][3][15] == 1.0f) static_cast<float *>(out_v)[0] = acc[1][2][3];
+        return;
+    }
     if (out_dtype != MBNB_F32) {
         char *wave_lds = smem + wave * 64 * 264;
         if (out_dtype == MBNB_F16) {
             epilogue_staged<T, f16_t, 4, 0>(acc, wave_lds, bias, static_cast<f16_t *>(out_v), M, N, m0 + wm * 128, n0 + wn * 128, lane_e);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // staging reads of the first half done before it is rewritten
             epilogue_staged<T, f16_t, 4, 2>(acc, wave_lds, bias, static_cast<f16_t *>(out_v), M, N, m0 + wm * 128 + 64, n0 + wn * 128, lane_e);
         } else {
             epilogue_staged<T, bf16_t, 4, 0>(acc, wave_lds, bias, static_cast<bf16_t *>(out_v), M, N, m0 + wm * 128, n0 + wn * 128, lane_e);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             epilogue_staged<T, bf16_t, 4, 2>(acc, wave_lds, bias, static_cast<bf16_t *>(out_v), M, N, m0 + wm * 128 + 64, n0 + wn * 128, lane_e);
         }
         return;
     }
+#endif
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
@@ -344,7 +409,8 @@ __global__ __launch_bounds__(256, 1) void k_gemm256q(const T *__restrict__ X, ty
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
-                    float s = acc[i][j][4 * g + e];
+                    float s;
+                    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(s) : "a"(acc[i][j][4 * g + e]));
                     if (bias != nullptr && nn + e < N) s += to_f32(bias[nn + e]);
                     v[e] = to_f32(from_f32<T>(s));
                 }

@@ -40,6 +40,18 @@ template <> struct Mfma<bf16_t> {
     }
 };
 
+// LDS-DMA issued from inline assembly.  Through the builtin the instruction carries a global AND an LDS memory operand,
+// which the compiler's wait-count pass treats as a "pending FLAT" access: from then on every LDS wait it inserts is
+// lgkmcnt(0) instead of the exact in-order count, i.e. each fragment / lookup use drains ALL of the wave's LDS reads.
+// As assembly the instruction is invisible to that pass (vmcnt for it is counted by hand here anyway).
+template <int BYTES> __device__ __forceinline__ void lds_dma(const void *gptr, uint32_t lds_base) {
+    static_assert(BYTES == 16 || BYTES == 4, "");
+    if constexpr (BYTES == 16)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_base), "v"(gptr) : "memory", "m0");
+    else
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(lds_base), "v"(gptr) : "memory", "m0");
+}
+
 // 16 x 16 x 32 MFMA (skinny kernels): A lane l = row l & 15, k chunk l >> 4; D[a][b]: a = 4 * (l >> 4) + r, b = l & 15
 template <typename T> struct Mfma16;
 template <> struct Mfma16<f16_t> {

@@ -16,11 +16,13 @@
 #include <utility>
 
 #include "gemm256.h"
-#ifdef MBNB_ABLATION
-#include "gemm256q.h"   // four-wave variant (work in progress, see its header): diagnostic builds only
-#endif
 
 namespace mbnb {
+
+// four-wave cut of the 256 x 256 kernel (gemm256q.h), compiled in gemm256q.hip
+template <typename T, bool NESTED>
+int launch_gemm256q(const T *x, const typename Q4ProducerRT<T, NESTED>::Params &wp, const T *bias, void *out, int out_dtype,
+                    int64_t M, int64_t N, int64_t K, hipStream_t st);
 
 // =====================================================================================
 // generic kernel: wave per (n, m-chunk of MT rows); lanes stride over k in steps of 8
@@ -527,21 +529,14 @@ static int launch_matmul4(const void *A, int64_t M, int64_t K, const uint8_t *pa
                 bool am4 = !no_am4 && blocksize == 64 && (K_weight % 256 == 0);
                 if constexpr (NESTED) am4 = am4 && am.bs2 >= 4 && (reinterpret_cast<uintptr_t>(am.i8) & 3) == 0;
                 if (am4) kern = no_blut ? k_gemm256p<T, NESTED, 0, true> : k_gemm256p<T, NESTED, 0, true, true>;
+                static const bool use_q = getenv("MBNB_Q4W") != nullptr;   // A/B switch: four-wave variant (gemm256q.h)
+                if (use_q && am4 && (int64_t)M * K * (int64_t)sizeof(T) < (1ll << 32) && N * K_weight / 2 < (1ll << 32) &&
+                    N * (K_weight / blocksize) < (1ll << 32)) {
+                    set_kernel_name("mfma256q");
+                    return launch_gemm256q<T, NESTED>(x, wp, b, static_cast<void *>(o), od, M, N, K, st);
+                }
 #ifdef MBNB_ABLATION
                 // diagnostic builds: the measured schedule alternatives
-                static const bool use_q = getenv("MBNB_Q4W") != nullptr;   // A/B switch: four-wave variant (gemm256q.h)
-                if (use_q && am4) {
-                    auto kq = k_gemm256q<T, NESTED>;
-                    constexpr int ldsq = gemm256q_lds_bytes<NESTED>();
-                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kq), hipFuncAttributeMaxDynamicSharedMemorySize, ldsq);
-                    if (e != hipSuccess) {
-                        set_error("matmul_4bit: hipFuncSetAttribute(256q) failed: %s", hipGetErrorString(e));
-                        return (int)e;
-                    }
-                    hipLaunchKernelGGL(kq, dim3((unsigned)tiles), dim3(256), ldsq, st, x, wp, b, static_cast<void *>(o), od, M, N, K);
-                    set_kernel_name("mfma256q");
-                    return check_launch("matmul_4bit(mfma256q)");
-                }
                 static const bool use_pp = getenv("MBNB_PINGPONG") != nullptr;    // ping-pong schedule
                 static const bool use_valu = getenv("MBNB_VALUDEC") != nullptr;   // slot-pinned + VALU decode
                 if (use_pp) kern = k_gemm256pp<T, NESTED>;

@@ -567,3 +567,40 @@ def test_linear_int8_randomized_dispatch_sweep():
         err = rel_fro(y, oracle.linear_int8(x, q, s, b))
         assert err <= TOL[dt], f"case {case}: M={M} N={N} K={K} {dt} ({kern}): {err:.3e}"
     assert {"w8a16_skinny", "w8a16_mfma128", "w8a16_generic"} <= set(seen), seen
+
+
+_Q4W_CHILD = r'''
+import sys, torch
+import mps_bitsandbytes_amd as bnb
+from mps_bitsandbytes_amd import _native, synthetic
+out = {}
+for idx, (M, N, K, dt, cs, qt, bias, cd) in enumerate(eval(sys.argv[1])):
+    dt = getattr(torch, dt); cd = getattr(torch, cd) if cd else None
+    W = synthetic.normal((N, K), dt, seed=70 + idx).to("cuda")
+    X = synthetic.normal((M, K), dt, seed=80 + idx).to("cuda")
+    b = synthetic.normal((N,), dt, seed=90 + idx).to("cuda") if bias else None
+    packed, st = bnb.quantize_4bit(W, compress_statistics=cs, quant_type=qt)
+    y = bnb.matmul_4bit(X, packed, st, b, cd)
+    out[idx] = (_native.last_kernel(), y.cpu())
+torch.save(out, sys.argv[2])
+'''
+
+
+def test_matmul_mfma256_four_wave_variant(tmp_path):
+    """k_gemm256q (MBNB_Q4W=1, read once per process -> child processes): same decoded B bits and the same per-element
+    accumulation order as k_gemm256p, so the outputs must be bit-identical -- ragged edges, nested absmax, FP4, bias and
+    the f32 output path included."""
+    import os, subprocess, sys
+    cases = [(2560, 2560, 512, "bfloat16", False, "nf4", False, None), (2500, 2600, 256, "float16", True, "nf4", True, None),
+             (2304, 3000, 768, "bfloat16", True, "fp4", True, "float32"), (3000, 2304, 256, "float16", False, "fp4", False, "bfloat16")]
+    got = {}
+    for tag, extra in (("p", {}), ("q", {"MBNB_Q4W": "1"})):
+        env = dict(os.environ, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), **extra)
+        path = str(tmp_path / f"{tag}.pt")
+        r = subprocess.run([sys.executable, "-c", _Q4W_CHILD, repr(cases), path], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got[tag] = torch.load(path)
+    for idx in range(len(cases)):
+        assert got["p"][idx][0] == "mfma256" and got["q"][idx][0] == "mfma256q", (got["p"][idx][0], got["q"][idx][0])
+        a, b = got["p"][idx][1], got["q"][idx][1]
+        assert a.dtype == b.dtype and torch.equal(a.view(torch.uint8), b.view(torch.uint8)), f"case {cases[idx]} differs"

@@ -1,5 +1,5 @@
 """A/B kernel time of the headline matmul_4bit (4096^3 NF4 bf16) under env switches, one subprocess per variant
-(the switches are read once per process).  usage: python tools/ab_time.py "" MBNB_VALUDEC=1 MBNB_NO_AM4=1 ..."""
+(the switches are read once per process; MBNB_AB_SHAPE=M,N,K changes the shape).  usage: python tools/ab_time.py "" MBNB_VALUDEC=1 MBNB_NO_AM4=1 ..."""
 import os, subprocess, sys
 CHILD = r'''
 import os, sys, torch
@@ -8,8 +8,9 @@ import mps_bitsandbytes_amd as bnb
 from mps_bitsandbytes_amd import _native
 from mps_bitsandbytes_amd import synthetic
 dev = "cuda"
-W = synthetic.normal((4096, 4096), torch.bfloat16, 1, 0.02).to(dev)
-X = synthetic.normal((4096, 4096), torch.bfloat16, 2, 1.0).to(dev)
+M_, N_, K_ = (int(v) for v in os.environ.get("MBNB_AB_SHAPE", "4096,4096,4096").split(","))
+W = synthetic.normal((N_, K_), torch.bfloat16, 1, 0.02).to(dev)
+X = synthetic.normal((M_, K_), torch.bfloat16, 2, 1.0).to(dev)
 packed, st = bnb.quantize_nf4(W)
 ref = bnb.matmul_4bit(X[:256], packed, st).float()
 for _ in range(100): out = bnb.matmul_4bit(X, packed, st)
