@@ -8,18 +8,29 @@
 // has 512 registers (256 accumulators + 256).  Same LDS images, swizzle, LDS-DMA staging, byte-table decode
 // (bit-identical B operand) and absmax-by-4 fetch as k_gemm256p; requires blocksize 64 and K_weight % 256 == 0.
 //
-// Per wave and k-step: 64 MFMAs (4 groups of 16), 32 fragment reads, 8 activation DMA pieces, 2 raw pieces,
-// 8 decode quarters (2 passes of 32 rows x 2 halves).  Pipeline of tile j+1's decode inside step j:
-//   group 3 of step j-1: raw(j+1) -> registers, lookups of quarters 0,1
-//   group 0: products of 0,1 | lookups 2,3,4      group 1: products 2,3,4 | lookups 5,6,7      group 2: products 5,6,7
-// and one barrier per k-step between groups 2 and 3, as in k_gemm256p.
+// Per wave and k-step: 64 MFMAs in 4 groups of 16 slots (one MFMA + its fillers, fenced), 32 fragment reads, 8 activation
+// DMA pieces, 2 raw pieces, 8 decode quarters (2 passes of 32 rows x 2 halves); the slot plan is written out above
+// `kstep`.  One barrier per k-step between groups 2 and 3, as in k_gemm256p.
 //
-// STATUS (round 1): correct (parity tests pass with MBNB_Q4W=1 in a -DMBNB_ABLATION build) but not yet usable: with all
-// 256 AGPRs holding accumulators hipcc spills ~280 loop-spanning VGPRs (addresses, offsets) to scratch and reloads
-// them inside the k-step (50 scratch loads per two k-steps, each behind a vmcnt wait): 579 us vs 123 us for
-// k_gemm256p.  The loop itself peaks at only 168 VGPRs; the spills come from live-range splitting around the
-// prologue / epilogue peaks.  Next: per-phase kernels-within-a-kernel (noinline prologue / epilogue) or inline-asm
-// pinned address registers.
+// STATUS (round 1): correct and spill-free, opt-in (MBNB_Q4W=1; tests/test_gpu_parity.py runs it in a child process and
+// requires bit-identical outputs to k_gemm256p).  4096^3 bf16: 126-129 us vs 123-126 us for k_gemm256p -- the k-step is
+// faster (1.58 vs 1.69 us) but prologue + epilogue cost ~5 us more with half the waves.  What made it usable (579 us
+// before), all compiler-side:
+//  * the zero-filled accumulators were a loop-carried phi whose 256 zeros had to exist in VGPRs at loop entry (and, with
+//    a top-tested loop, stay reserved across it): ~280 spilled VGPRs.  Now the first MFMA group takes a literal-zero C
+//    operand and the first pair of k-steps is peeled -- no spill, no AGPR shuffling in the loop;
+//  * at the loop exit the allocator copied all 256 accumulators to VGPRs at once for the epilogue's VALU work and
+//    spilled what did not fit: the epilogue now pulls each value out of its AGPR where it is used (v_accvgpr_read_b32
+//    from inline assembly, gemm256.h epilogue_staged);
+//  * through __builtin_amdgcn_global_load_lds the LDS-DMA carries a global AND an LDS memory operand, which the
+//    wait-count pass books as a pending FLAT access: every later LDS wait becomes lgkmcnt(0).  Issued from inline
+//    assembly (lds_dma, gemm_tile.h) the waits come out as exact in-order counts (lgkmcnt(9), (13), (14) ...).
+// Ablation at 4096^3 (-DMBNB_Q_ABLATE, MBNB_QABL=bits: 1 decode, 2 activation DMA, 4 fragment reads, 8 MFMA, 64 epilogue):
+// MFMA + fragment reads 75 us, everything but the MFMAs 80 us, full kernel 127 us: with one wave per SIMD the MFMA stream
+// and the rest largely ADD UP instead of overlapping (activation DMA +25 us, decode +21 us on top of MFMA + fragments),
+// which is the case for two waves per SIMD (k_gemm256p) despite its higher LDS traffic.  Tried without gain: exact LDS
+// waits in k_gemm256p / k_gemm256w / k_gemm_i8_256 (two waves hide the drains), an L2 prefetch of the next k-steps' lines
+// by one wave per workgroup (+2 us), un-swizzled DMA sources (no change), per-wave staggered DMA issue (no change).
 #pragma once
 #include "gemm256.h"
 #include <utility>
@@ -115,10 +126,10 @@ __global__ __launch_bounds__(256, 1) void k_gemm256q(const T *__restrict__ X, ty
         bn = bn < N ? bn : N - 1;
         p_off[p] = (uint32_t)(((bn * wp.K_weight) >> 1) + 16 * b_half);
     }
-    auto issue_raw = [&](int rs, int64_t k0) {
+    auto issue_raw = [&](int rs, int64_t k0, int first = 0, int count = 2) {
         const uint8_t *pb = wp.packed + (k0 >> 1);   // uniform
 #pragma unroll
-        for (int p = 0; p < 2; p++) {
+        for (int p = first; p < first + count; p++) {
             auto g = (const __attribute__((address_space(1))) void *)(pb + p_off[p]);
             auto l = (__attribute__((address_space(3))) void *)(smem + P_RAW + rs * RAWQ + wave * 2048 + p * 1024);
             lds_dma<16>((const void *)g, (uint32_t)(uintptr_t)l);
@@ -302,11 +313,23 @@ __global__ __launch_bounds__(256, 1) void k_gemm256q(const T *__restrict__ X, ty
             __builtin_amdgcn_sched_barrier(0);
         });
     };
+    // LDS-DMA placement: the four waves leave each barrier in step, so a piece "at slot B" is issued by wave w at slot
+    // B + w -- one 1 KiB instruction per slot and CU instead of four at once (measured neutral at 4096^3, kept for the
+    // even load on the memory pipe).
+    auto at = [&](auto rr, auto bb, auto &&fn) {
+        constexpr int r = decltype(rr)::value, B = decltype(bb)::value;
+        if constexpr (r >= B && r < B + 4) {
+            if (wave == r - B) fn();
+        }
+    };
+    using S4 = std::integral_constant<int, 4>;
+    using S8 = std::integral_constant<int, 8>;
+    using S12 = std::integral_constant<int, 12>;
     auto kstep = [&](auto cc, auto first, int64_t j) {
         constexpr int C = decltype(cc)::value, Nn = C ^ 1;
         constexpr bool FIRST = decltype(first)::value;
         using PC = std::integral_constant<int, C>;
-        const int64_t k1 = kclamp(j + 1), k2 = kclamp(j + 2);
+        const int64_t k1 = kclamp(j + 1), k2 = kclamp(j + 2), k3 = kclamp(j + 3);
         group(wfA, xfA, first, [&](auto rr) {
             constexpr int r = decltype(rr)::value;
             if constexpr (r < 4) read_frag_pair(C, 1, r, wfB, xfB);
@@ -317,7 +340,11 @@ __global__ __launch_bounds__(256, 1) void k_gemm256q(const T *__restrict__ X, ty
             if constexpr (r == 9) finish_b(L[0], ram[Nn][0], 0, 0, Nn);
             if constexpr (r == 10) finish_a(L[1], ram[Nn][0]);
             if constexpr (r == 11) finish_b(L[1], ram[Nn][0], 0, 1, Nn);
-            if constexpr (!FIRST && (r == 12 || r == 13)) issue_a(Nn, k1, r - 8, 1);
+            if constexpr (!FIRST) {
+                at(rr, S4{}, [&] { issue_a(Nn, k1, 3, 1); });
+                at(rr, S8{}, [&] { issue_a(Nn, k1, 4, 1); });
+                at(rr, S12{}, [&] { issue_a(Nn, k1, 5, 1); });
+            }
         });
         group(wfB, xfB, std::false_type{}, [&](auto rr) {
             constexpr int r = decltype(rr)::value;
@@ -331,7 +358,10 @@ __global__ __launch_bounds__(256, 1) void k_gemm256q(const T *__restrict__ X, ty
             if constexpr (r == 10) finish_b(L[3], ram[Nn][0], 0, 3, Nn);
             if constexpr (r == 11) finish_a(L[4], ram[Nn][1]);
             if constexpr (r == 12) finish_b(L[4], ram[Nn][1], 1, 0, Nn);
-            if constexpr (!FIRST && (r == 13 || r == 14)) issue_a(Nn, k1, r - 7, 1);
+            if constexpr (!FIRST) {
+                at(rr, S4{}, [&] { issue_a(Nn, k1, 6, 1); });
+                at(rr, S8{}, [&] { issue_a(Nn, k1, 7, 1); });
+            }
         });
         const bool am_now = ((j + 3) & 3) == 0;
         group(wfA, xfA, std::false_type{}, [&](auto rr) {
@@ -343,8 +373,9 @@ __global__ __launch_bounds__(256, 1) void k_gemm256q(const T *__restrict__ X, ty
             if constexpr (r == 7) finish_b(L[6], ram[Nn][1], 1, 2, Nn);
             if constexpr (r == 8) finish_a(L[7], ram[Nn][1]);
             if constexpr (r == 9) finish_b(L[7], ram[Nn][1], 1, 3, Nn);
-            if constexpr (r == 10) issue_raw(Nn, kclamp(j + 3));
-            if constexpr (r == 11) { if (am_now) issue_am4((j + 3) >> 2); }
+            at(rr, S4{}, [&] { issue_raw(Nn, k3, 0, 1); });
+            at(rr, S8{}, [&] { issue_raw(Nn, k3, 1, 1); });
+            at(rr, S12{}, [&] { if (am_now) issue_am4((j + 3) >> 2); });
         });
         // everything but what this group just issued has landed: A(j+1), raw(j+2), older absmax blocks
         if (am_now) { if constexpr (NESTED) MBNB_VMCNT(4); else MBNB_VMCNT(3); } else { MBNB_VMCNT(2); }
@@ -356,7 +387,9 @@ __global__ __launch_bounds__(256, 1) void k_gemm256q(const T *__restrict__ X, ty
             constexpr int r = decltype(rr)::value;
             if constexpr (r < 4) read_frag_pair(Nn, 0, r, wfA, xfA);
             if constexpr (r == 4) load_raw(PC{}, j + 2);
-            if constexpr (r >= 5 && r <= 8) issue_a(C, k2, r - 5, 1);
+            at(rr, S4{}, [&] { issue_a(C, k2, 0, 1); });
+            at(rr, S8{}, [&] { issue_a(C, k2, 1, 1); });
+            at(rr, S12{}, [&] { issue_a(C, k2, 2, 1); });
             if constexpr (r == 10) lookup_q(rw[C][0][0], L[0]);
             if constexpr (r == 12) lookup_q(rw[C][0][1], L[1]);
         });
