@@ -53,21 +53,60 @@ __device__ __forceinline__ void load8(const T *A, int64_t rows, int64_t cols, in
 // |xn| among the non-negative codes, then index 8 + j for negative inputs -- except j = 0: -0.0 (index 8) ties with
 // +0.0 (index 0) and the first minimum wins, so index 8 is never produced.  NaN compares false everywhere -> 0, as
 // torch.argmin over all-NaN distances.
+constexpr uint32_t NF4_THR_BITS[15] = {0xbf591cd9u, 0xbf1c5271u, 0xbeeb8480u, 0xbeadea77u, 0xbe703cedu, 0xbe0d38bcu, 0xbd3a7871u,
+                                       0x3d22faffu, 0x3df64862u, 0x3e5067e0u, 0x3e9582d4u, 0x3ec753f9u, 0x3f006d03u, 0x3f248dafu,
+                                       0x3f5c89d9u};
+constexpr float FP4_THR[7] = {0.03125f, 0.09375f, 0.1875f, 0.3125f, 0.4375f, 0.625f, 0.875f};
+
 template <int QT> __device__ __forceinline__ uint32_t nearest_code(float xn) {
     if constexpr (QT == MBNB_NF4) {
-        constexpr uint32_t T[15] = {0xbf591cd9u, 0xbf1c5271u, 0xbeeb8480u, 0xbeadea77u, 0xbe703cedu, 0xbe0d38bcu, 0xbd3a7871u,
-                                    0x3d22faffu, 0x3df64862u, 0x3e5067e0u, 0x3e9582d4u, 0x3ec753f9u, 0x3f006d03u, 0x3f248dafu,
-                                    0x3f5c89d9u};
         uint32_t idx = 0;
 #pragma unroll
-        for (int i = 0; i < 15; i++) idx += (xn > __builtin_bit_cast(float, T[i])) ? 1u : 0u;
+        for (int i = 0; i < 15; i++) idx += (xn > __builtin_bit_cast(float, NF4_THR_BITS[i])) ? 1u : 0u;
         return idx;
     } else {
-        constexpr float U[7] = {0.03125f, 0.09375f, 0.1875f, 0.3125f, 0.4375f, 0.625f, 0.875f};
         const float a = fabsf(xn);
         uint32_t j = 0;
 #pragma unroll
-        for (int i = 0; i < 7; i++) j += (a > U[i]) ? 1u : 0u;
+        for (int i = 0; i < 7; i++) j += (a > FP4_THR[i]) ? 1u : 0u;
+        return (xn < 0.0f && j > 0) ? 8u + j : j;
+    }
+}
+
+// The same count with a first guess from LDS: 256 bins over xn in [-1, 1) (NF4) / |xn| in [0, 1) (FP4) hold the number
+// of thresholds safely below the bin; at most one more can lie at or inside it (tools/gen_code_thresholds.py builds and
+// checks the tables, code_bins.inc), so one exact compare against that threshold finishes the count: 2 LDS reads and
+// ~6 VALU instead of 30 VALU per element -- the quantize kernel is VALU-bound, not HBM-bound.
+#include "code_bins.inc"
+template <int QT> __device__ __forceinline__ float code_threshold(int i) {   // thresholds padded with +inf
+    float t = __builtin_inff();
+    if constexpr (QT == MBNB_NF4) {
+#pragma unroll
+        for (int k = 0; k < 15; k++)
+            if (i == k) t = __builtin_bit_cast(float, NF4_THR_BITS[k]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 7; k++)
+            if (i == k) t = FP4_THR[k];
+    }
+    return t;
+}
+template <int QT> __device__ __forceinline__ void fill_code_bins(uint8_t *bins, float *thr, int tid) {   // 256 threads
+    bins[tid] = (QT == MBNB_NF4) ? g_nf4_bins[tid] : g_fp4_bins[tid];
+    if (tid < 16) thr[tid] = code_threshold<QT>(tid);
+}
+template <int QT> __device__ __forceinline__ uint32_t nearest_code_lut(float xn, const uint8_t *bins, const float *thr) {
+    if constexpr (QT == MBNB_NF4) {
+        int b = (int)__builtin_fmaf(xn, 128.0f, 128.0f);
+        b = b < 0 ? 0 : (b > 255 ? 255 : b);
+        const uint32_t low = bins[b];
+        return low + ((xn > thr[low]) ? 1u : 0u);
+    } else {
+        const float a = fabsf(xn);
+        int b = (int)(a * 256.0f);
+        b = b < 0 ? 0 : (b > 255 ? 255 : b);
+        const uint32_t low = bins[b];
+        const uint32_t j = low + ((a > thr[low]) ? 1u : 0u);
         return (xn < 0.0f && j > 0) ? 8u + j : j;
     }
 }
@@ -78,6 +117,10 @@ __global__ __launch_bounds__(256) void k_quantize_4bit(const T *__restrict__ A, 
                                                       const float *__restrict__ absmax_in,
                                                       uint8_t *__restrict__ packed,
                                                       float *__restrict__ absmax_out, bool vec_ok) {
+    __shared__ uint8_t s_bins[256];
+    __shared__ float s_thr[16];
+    fill_code_bins<QT>(s_bins, s_thr, threadIdx.x);
+    __syncthreads();
     // one wave handles `span` = max(blocksize, 512) consecutive padded elements of one row
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -114,7 +157,7 @@ __global__ __launch_bounds__(256) void k_quantize_4bit(const T *__restrict__ A, 
         if ((lane & (team - 1)) == 0) absmax_out[r * nblk + blk] = am;
         uint32_t w = 0;
 #pragma unroll
-        for (int j = 0; j < 8; j++) w |= nearest_code<QT>(x[j] / am) << (4 * j);
+        for (int j = 0; j < 8; j++) w |= nearest_code_lut<QT>(x[j] / am, s_bins, s_thr) << (4 * j);
         *reinterpret_cast<uint32_t *>(packed + (r * cols_padded + k0) / 2) = w;
     } else {
         // block larger than one wave step: pass 1 absmax over the block, pass 2 quantise
@@ -139,7 +182,7 @@ __global__ __launch_bounds__(256) void k_quantize_4bit(const T *__restrict__ A, 
             load8<T>(A, rows, cols, r, k0, vec_ok, x);
             uint32_t w = 0;
 #pragma unroll
-            for (int j = 0; j < 8; j++) w |= nearest_code<QT>(x[j] / am) << (4 * j);
+            for (int j = 0; j < 8; j++) w |= nearest_code_lut<QT>(x[j] / am, s_bins, s_thr) << (4 * j);
             *reinterpret_cast<uint32_t *>(packed + (r * cols_padded + k0) / 2) = w;
         }
     }

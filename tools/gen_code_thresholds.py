@@ -71,6 +71,49 @@ def check(table, thr, fp4):
     return x.size
 
 
+def bin_table(thr, lo, scale):
+    """256-bin first guess for the threshold count: bin b = int(x * scale + 256 * lo_off) covers [e_b, e_b+1).  The kernel
+    computes the bin with one fma (error < 2^-24 in x near a bin edge), so idx_low[b] counts the thresholds safely below
+    the bin (< e_b - 2^-23) and at most ONE further threshold may lie below e_{b+1} + 2^-23: the kernel settles it with one
+    exact compare, idx = idx_low + (x > thr[idx_low]) (thr padded with +inf)."""
+    thr = np.asarray(thr, dtype=np.float64)
+    out = []
+    for b in range(256):
+        e0, e1 = lo + b / scale, lo + (b + 1) / scale
+        low = int((thr < e0 - 2.0 ** -23).sum())
+        assert int((thr < e1 + 2.0 ** -23).sum()) - low <= 1, (b, e0, e1)
+        out.append(low)
+    return np.array(out, dtype=np.uint8)
+
+
+def check_bins(thr, table, lo, scale, absolute):
+    rng = np.random.default_rng(1)
+    pts = [rng.uniform(-1.001, 1.001, 2_000_000).astype(np.float32), np.float32([-1.0, 1.0, 0.0, -0.0, 2.0, -2.0])]
+    for c in thr:
+        k = int(f2i(np.float32(c)))
+        pts.append(i2f(np.arange(k - 4096, k + 4097)))
+    for b in range(257):   # every bin edge and its f32 neighbourhood
+        k = int(f2i(np.float32(lo + b / scale)))
+        pts.append(i2f(np.arange(k - 64, k + 65)))
+    x = np.concatenate(pts).astype(np.float32)
+    a = np.abs(x) if absolute else x
+    want = (a[:, None] > thr[None, :]).sum(axis=1)
+    # the kernel's bin: fl(a * scale + off) in f32 (one rounding, fma), truncated, clamped to 0..255
+    y = (a.astype(np.float64) * scale - lo * scale).astype(np.float32)
+    b = np.clip(np.trunc(y).astype(np.int64), 0, 255)
+    low = table[b].astype(np.int64)
+    pad = np.concatenate([thr, np.float32([np.inf])]).astype(np.float32)
+    got = low + (a > pad[low])
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, (x[bad[:5]], got[bad[:5]], want[bad[:5]])
+    return x.size
+
+
+def c_array(name, t):
+    rows = [", ".join(str(int(v)) for v in t[i:i + 32]) for i in range(0, 256, 32)]
+    return f"static __device__ const uint8_t {name}[256] = {{\n    " + ",\n    ".join(rows) + "};"
+
+
 if __name__ == "__main__":
     nf4_thr = np.array([threshold(NF4[i], NF4[i + 1]) for i in range(15)], dtype=np.float32)
     fp4_thr = np.array([threshold(FP4_POS[i], FP4_POS[i + 1]) for i in range(7)], dtype=np.float32)
@@ -78,3 +121,13 @@ if __name__ == "__main__":
     print(f"// verified against the brute-force argmin on {n1} (NF4) / {n2} (FP4) f32 values")
     print("NF4:", ", ".join(f"{float(t):.9g}f /*0x{np.float32(t).view(np.uint32):08x}*/" for t in nf4_thr))
     print("FP4:", ", ".join(f"{float(t):.9g}f /*0x{np.float32(t).view(np.uint32):08x}*/" for t in fp4_thr))
+    # first-guess bin tables of nearest_code_lut: NF4 on xn in [-1, 1) (bin = xn * 128 + 128), FP4 on |xn| (bin = |xn| * 256)
+    nf4_bins, fp4_bins = bin_table(nf4_thr, -1.0, 128.0), bin_table(fp4_thr, 0.0, 256.0)
+    m1, m2 = check_bins(nf4_thr, nf4_bins, -1.0, 128.0, False), check_bins(fp4_thr, fp4_bins, 0.0, 256.0, True)
+    import os
+    inc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "mps_bitsandbytes_amd", "csrc", "code_bins.inc")
+    with open(inc, "w") as f:
+        f.write("// generated by tools/gen_code_thresholds.py -- first-guess bins of nearest_code_lut (quant_kernels.hip);\n"
+                f"// the bin rule was checked against the threshold count on {m1} (NF4) / {m2} (FP4) f32 values\n")
+        f.write(c_array("g_nf4_bins", nf4_bins) + "\n" + c_array("g_fp4_bins", fp4_bins) + "\n")
+    print("wrote", os.path.normpath(inc))
