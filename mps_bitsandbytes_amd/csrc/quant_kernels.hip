@@ -116,20 +116,27 @@ __global__ __launch_bounds__(256) void k_quantize_4bit(const T *__restrict__ A, 
                                                       int64_t cols_padded, int blocksize,
                                                       const float *__restrict__ absmax_in,
                                                       uint8_t *__restrict__ packed,
-                                                      float *__restrict__ absmax_out, bool vec_ok) {
+                                                      float *__restrict__ absmax_out, bool vec_ok, bool row_grid) {
     __shared__ uint8_t s_bins[256];
     __shared__ float s_thr[16];
     fill_code_bins<QT>(s_bins, s_thr, threadIdx.x);
     __syncthreads();
     // one wave handles `span` = max(blocksize, 512) consecutive padded elements of one row
     const int lane = threadIdx.x & 63;
-    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int span = blocksize > 512 ? blocksize : 512;
     const int64_t spans_per_row = (cols_padded + span - 1) / span;
-    const int64_t total = rows * spans_per_row;
-    if (wave >= total) return;
-    const int64_t r = wave / spans_per_row;
-    const int64_t kspan = (wave % spans_per_row) * span;
+    int64_t r, kspan;
+    if (row_grid) {   // blockIdx.x = row, blockIdx.y = group of four spans: no 64-bit divisions per thread
+        const int64_t sp = (int64_t)blockIdx.y * 4 + (threadIdx.x >> 6);
+        if (sp >= spans_per_row) return;
+        r = blockIdx.x;
+        kspan = sp * span;
+    } else {
+        const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+        if (wave >= rows * spans_per_row) return;
+        r = wave / spans_per_row;
+        kspan = (wave % spans_per_row) * span;
+    }
     const int64_t nblk = cols_padded / blocksize;
 
     if (blocksize <= 512) {
@@ -228,15 +235,23 @@ __global__ __launch_bounds__(256) void k_quantize_4bit_tiny(const T *__restrict_
 template <typename T, int QT, bool NESTED>
 __global__ __launch_bounds__(256) void k_dequantize_4bit(const uint8_t *__restrict__ packed, AbsmaxView am,
                                                         int64_t rows, int64_t cols, int64_t cols_padded,
-                                                        int blocksize, T *__restrict__ out, bool vec_ok) {
+                                                        int blocksize, T *__restrict__ out, bool vec_ok, bool row_grid) {
     __shared__ float lut[16];
     fill_code_lut<QT>(lut, threadIdx.x);
     __syncthreads();
     const int64_t groups_per_row = (cols + 7) / 8;
-    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= rows * groups_per_row) return;
-    const int64_t r = g / groups_per_row;
-    const int64_t k0 = (g % groups_per_row) * 8;
+    int64_t r, k0;
+    if (row_grid) {   // blockIdx.x = row, blockIdx.y = 256 groups of 8 values: no 64-bit divisions per thread
+        const int64_t gc = (int64_t)blockIdx.y * 256 + threadIdx.x;
+        if (gc >= groups_per_row) return;
+        r = blockIdx.x;
+        k0 = gc * 8;
+    } else {
+        const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (g >= rows * groups_per_row) return;
+        r = g / groups_per_row;
+        k0 = (g % groups_per_row) * 8;
+    }
     const int64_t nblk = cols_padded / blocksize;
     const int64_t flat0 = r * cols_padded + k0;  // even (cols_padded even, k0 multiple of 8)
     float v[8];
@@ -503,14 +518,17 @@ static int launch_quantize_4bit(const void *A, int64_t rows, int64_t cols, int64
     }
     const bool vec_ok = aligned16(A) && (cols % 8 == 0);
     const int span = blocksize > 512 ? blocksize : 512;
-    const int64_t waves = rows * ((cols_padded + span - 1) / span);
-    const unsigned grid = (unsigned)((waves + 3) / 4);
+    const int64_t spans_per_row = (cols_padded + span - 1) / span;
+    const int64_t waves = rows * spans_per_row;
+    // wide rows: one grid row per matrix row (no per-thread division); narrow ones keep the flat wave index
+    const bool row_grid = spans_per_row >= 4 && (spans_per_row + 3) / 4 <= 65535 && rows <= 0x7FFFFFFF;
+    const dim3 grid = row_grid ? dim3((unsigned)rows, (unsigned)((spans_per_row + 3) / 4)) : dim3((unsigned)((waves + 3) / 4));
     if (qt == MBNB_NF4)
-        hipLaunchKernelGGL((k_quantize_4bit<T, MBNB_NF4>), dim3(grid), dim3(256), 0, st, a, rows, cols, cols_padded,
-                           blocksize, absmax_in, packed, absmax_out, vec_ok);
+        hipLaunchKernelGGL((k_quantize_4bit<T, MBNB_NF4>), grid, dim3(256), 0, st, a, rows, cols, cols_padded,
+                           blocksize, absmax_in, packed, absmax_out, vec_ok, row_grid);
     else
-        hipLaunchKernelGGL((k_quantize_4bit<T, MBNB_FP4>), dim3(grid), dim3(256), 0, st, a, rows, cols, cols_padded,
-                           blocksize, absmax_in, packed, absmax_out, vec_ok);
+        hipLaunchKernelGGL((k_quantize_4bit<T, MBNB_FP4>), grid, dim3(256), 0, st, a, rows, cols, cols_padded,
+                           blocksize, absmax_in, packed, absmax_out, vec_ok, row_grid);
     return check_launch("quantize_4bit");
 }
 
@@ -527,15 +545,17 @@ int quantize_4bit_dispatch(const void *A, int dtype, int64_t rows, int64_t cols,
 template <typename T, int QT>
 static int launch_dequantize_4bit(const uint8_t *packed, const AbsmaxView &am, int64_t rows, int64_t cols,
                                   int64_t cols_padded, int blocksize, void *out, hipStream_t st) {
-    const int64_t groups = rows * ((cols + 7) / 8);
-    const unsigned grid = (unsigned)((groups + 255) / 256);
+    const int64_t gpr = (cols + 7) / 8;
+    const int64_t groups = rows * gpr;
+    const bool row_grid = gpr >= 256 && (gpr + 255) / 256 <= 65535 && rows <= 0x7FFFFFFF;
+    const dim3 grid = row_grid ? dim3((unsigned)rows, (unsigned)((gpr + 255) / 256)) : dim3((unsigned)((groups + 255) / 256));
     const bool vec_ok = aligned16(out) && (cols % 8 == 0);
     if (am.i8)
-        hipLaunchKernelGGL((k_dequantize_4bit<T, QT, true>), dim3(grid), dim3(256), 0, st, packed, am, rows, cols,
-                           cols_padded, blocksize, static_cast<T *>(out), vec_ok);
+        hipLaunchKernelGGL((k_dequantize_4bit<T, QT, true>), grid, dim3(256), 0, st, packed, am, rows, cols,
+                           cols_padded, blocksize, static_cast<T *>(out), vec_ok, row_grid);
     else
-        hipLaunchKernelGGL((k_dequantize_4bit<T, QT, false>), dim3(grid), dim3(256), 0, st, packed, am, rows, cols,
-                           cols_padded, blocksize, static_cast<T *>(out), vec_ok);
+        hipLaunchKernelGGL((k_dequantize_4bit<T, QT, false>), grid, dim3(256), 0, st, packed, am, rows, cols,
+                           cols_padded, blocksize, static_cast<T *>(out), vec_ok, row_grid);
     return check_launch("dequantize_4bit");
 }
 
