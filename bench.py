@@ -2,9 +2,14 @@
 """
 bench.py — throughput of the fused NF4 dequant + matmul hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: N child ranks are started)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
+
+Timing: a disclosed time-based pre-warm ("prewarm_ms": the clock needs a few hundred ms of load to settle),
+W untimed warm-up steps, then R = 5 repetitions of the K-step loop, each bracketed by barrier + synchronize on both
+sides and reduced with MAX over ranks; `value` and `ms_per_step` come from the MEDIAN repetition, and the kernel's
+launch duration (`roofline.kernel_us`) from HIP events recorded inside that same repetition on the launching stream.
 
 One "step" = one pass of the hot path over one batch: Linear4bit-style fused NF4 dequant + matmul,
 weight 4096x4096 (bf16-origin, blocksize 64), M = 4096 rows per GPU, bf16 activations, inputs
@@ -52,6 +57,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemv", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
+    ap.add_argument("--prewarm-ms", type=float, default=400.0, help="untimed, time-based load before the warm-up steps")
+    ap.add_argument("--reps", type=int, default=5, help="repetitions of the K-step loop; the median one is reported")
+    ap.add_argument("--chunks", type=int, default=2, help="N>1: row chunks of the `chunked` curve (GEMM chunk i+1 under the gather of chunk i)")
+    ap.add_argument("--verify", action="store_true", help="N>1: check gathered output == unsharded result on rank 0")
     return ap.parse_args()
 
 
@@ -223,14 +232,142 @@ def cpu_baseline(args, M, N, K, blocksize, compress, dtype):
                       f"OpenMP {threads} threads on {os.cpu_count()} logical cpus; C port of the reference's CPU path (oracle/)"}
 
 
+
+
+def cpu_baseline_gemv(args, N, K, dtype):
+    """M = 1 decode shape on the host cores: the oracle's matmul_4bit on one activation row, rotating over 8 layers
+    (75 MB of packed weights + absmax, beyond the host's L2) for ~cpu_seconds; GB/s of the same algorithmic bytes."""
+    import oracle
+    from mps_bitsandbytes_amd import synthetic
+    threads = oracle.num_threads()
+    layers = []
+    for i in range(8):
+        W = synthetic.normal((N, K), dtype, seed=1234 + i)
+        layers.append(oracle.quantize_4bit(W, 64, "nf4", False))
+    X = synthetic.normal((1, K), dtype, seed=4321)
+    nbytes = N * K // 2 + N * (K // 64) * 4 + K * 2 + N * 2
+    calls, spent = 0, 0.0
+    while spent < min(args.cpu_seconds, 10.0) and calls < 4096:
+        t0 = time.perf_counter()
+        for packed, absmax, st2 in layers:
+            oracle.matmul_4bit(X, packed, absmax, (N, K), 64, "nf4", dtype, None, None, st2)
+        spent += time.perf_counter() - t0
+        calls += len(layers)
+    return {"value": round(nbytes * calls / spent / 1e9, 3), "unit": "GB/s", "cores": threads, "kind": "port",
+            "sample": f"{calls} M=1 calls over 8 rotating {N}x{K} layers, {spent:.1f} s of CPU time, OpenMP {threads} threads; "
+                      f"C port of the reference's CPU path (oracle/)"}
+
+
+def cpu_baseline_int8(args, M, N, K):
+    """matmul_int8 on the host cores: the oracle's restatement of functional.py:788-793 on a row sample of the workload."""
+    import oracle
+    threads = oracle.num_threads()
+    gcpu = torch.Generator()
+    gcpu.manual_seed(4321)
+    rows = 256
+    A = torch.randint(-127, 128, (rows, K), generator=gcpu, dtype=torch.int8)
+    B = torch.randint(-127, 128, (K, N), generator=gcpu, dtype=torch.int8)
+    sa = torch.rand(rows, generator=gcpu) + 0.5
+    sb = torch.rand(N, generator=gcpu) + 0.5
+    oracle.matmul_int8(A[:16], B, sa[:16], sb, torch.float16)
+    reps, spent = 0, 0.0
+    while spent < min(args.cpu_seconds, 10.0) and reps < 256:
+        t0 = time.perf_counter()
+        oracle.matmul_int8(A, B, sa, sb, torch.float16)
+        spent += time.perf_counter() - t0
+        reps += 1
+    return {"value": round(2.0 * rows * N * K * reps / spent / 1e12, 5), "unit": "TOP/s", "cores": threads, "kind": "port",
+            "sample": f"{reps} x {rows} of the {M} rows against the full {K}x{N} B, {spent:.1f} s of CPU time, OpenMP {threads} threads (oracle/)"}
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes (torch.distributed.run, one
+    per GPU) before this process has made any GPU call, relay their output and exit with their status."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+class Timer:
+    """The timed region of the contract: barrier + synchronize, K steps, [finish], synchronize + barrier, MAX over
+    ranks -- repeated `reps` times; HIP events recorded on the launching stream inside each repetition give the
+    device-side duration of the same K launches."""
+
+    def __init__(self, distributed, dist, reduce_dev):
+        self.distributed, self.dist, self.reduce_dev = distributed, dist, reduce_dev
+
+    def _fence(self):
+        torch.cuda.synchronize()
+        if self.distributed:
+            self.dist.barrier()
+        torch.cuda.synchronize()
+
+    def prewarm(self, step, finish, ms):
+        t0 = time.perf_counter()
+        n = 0
+        while (time.perf_counter() - t0) * 1e3 < ms:
+            for _ in range(8):
+                step()
+            n += 8
+            if finish is not None:
+                finish()
+            torch.cuda.synchronize()
+        return n
+
+    def run(self, step, finish, steps, reps):
+        out = []
+        st = torch.cuda.current_stream()
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self._fence()
+            t0 = time.perf_counter()
+            e0.record(st)
+            for _ in range(steps):
+                step()
+            e1.record(st)
+            if finish is not None:
+                finish()
+            self._fence()
+            elapsed = time.perf_counter() - t0
+            ev_ms = e0.elapsed_time(e1)
+            if self.distributed:
+                t = torch.tensor([elapsed, ev_ms], dtype=torch.float64, device=self.reduce_dev)
+                self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+                elapsed, ev_ms = float(t[0].item()), float(t[1].item())
+            out.append((elapsed, ev_ms))
+        return out
+
+
+def median_rep(reps):
+    """(wall seconds, event ms) of the repetition with the median wall time"""
+    order = sorted(range(len(reps)), key=lambda i: reps[i][0])
+    return reps[order[len(order) // 2]]
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)   # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(json.dumps({"error": f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU"}))
+        sys.exit(2)
     distributed = world > 1
     if not torch.cuda.is_available():
-        print(json.dumps({"error": "no GPU visible; bench.py measures the HIP path only"}))
+        print(json.dumps({"error": "no GPU visible; bench.py measures the HIP path only", "rank": rank, "world": world}), flush=True)
         sys.exit(2)
     # BENCH_REHEARSE=1: every rank uses cuda:0 and the gloo backend -- lets the N > 1 code path be exercised on a
     # one-GPU box (RCCL refuses two ranks on one device); numbers from such a run mean nothing.
@@ -239,6 +376,7 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    dist = None
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -249,7 +387,7 @@ def main():
 
     import mps_bitsandbytes_amd as bnb
     from mps_bitsandbytes_amd import _native, synthetic
-    from mps_bitsandbytes_amd.sharding import row_shard
+    from mps_bitsandbytes_amd.sharding import ChunkedGather, row_shard
     _native.lib()  # fail loudly when the HIP library is missing
 
     wl = args.workload
@@ -268,55 +406,82 @@ def main():
 
     M_global = M * world
     s_row, e_row = row_shard(M_global, rank, world)
+    gw = torch.Generator(device=dev)
+    gw.manual_seed(1234)            # the replicated weight: the same on every rank
     g = torch.Generator(device=dev)
-    g.manual_seed(4321 + rank)
+    g.manual_seed(4321 + rank)      # this rank's rows of the global batch
 
     out = {"metric": None, "value": None, "unit": None, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": name,
            "data": "synthetic"}
+    timer = Timer(distributed, dist, "cpu" if rehearse else dev)
+    reps_n = max(1, args.reps)
 
-    gathered = None
+    do_gather = distributed and not args.no_gather and wl in ("nf4_m4096", "nf4dq_ffn")
+    modes = {}        # name -> (step, finish)
     if wl in ("nf4_m4096", "nf4dq_ffn", "nf4_m1"):
         std = 1.0 if wl != "nf4dq_ffn" else 0.02
-        W = (torch.randn(N, K, generator=g, device=dev, dtype=torch.float32) * std).to(dt)
+        W = (torch.randn(N, K, generator=gw, device=dev, dtype=torch.float32) * std).to(dt)
         if wl == "nf4_m1":
             # rotate over 64 distinct layers so the weights come from HBM, not the Infinity Cache
             layers = []
             for i in range(64):
-                Wi = (torch.randn(N, K, generator=g, device=dev, dtype=torch.float32)).to(dt)
+                Wi = (torch.randn(N, K, generator=gw, device=dev, dtype=torch.float32)).to(dt)
                 layers.append(bnb.quantize_nf4(Wi, blocksize=64))
                 del Wi
             X = torch.randn(1, K, generator=g, device=dev, dtype=torch.float32).to(dt)
-            ys = torch.empty(64, N, dtype=dt, device=dev)
 
             def step():
                 for p, st in layers:
                     bnb.matmul_4bit(X, p, st)
+            modes["main"] = (step, None)
             flops_per_step = 2.0 * N * K * 64
             bytes_per_launch = N * K // 2 + N * (K // 64) * 4 + K * 2 + N * 2   # 9 453 568 B
         else:
             packed, state = bnb.quantize_nf4(W, blocksize=64, compress_statistics=compress)
             del W
             X = torch.randn(e_row - s_row, K, generator=g, device=dev, dtype=torch.float32).to(dt)
-            if distributed and not args.no_gather:
-                # two result buffers: the all-gather of step i (RCCL's own stream, async_op) overlaps the GEMM of
-                # step i+1; a buffer is reused only after the gather that filled it two steps earlier has completed
-                gathered = [torch.empty(M_global, N, dtype=dt, device=dev) for _ in range(2)]
-            pending = [None, None]
-            counter = [0]
 
-            def step():
-                y = bnb.matmul_4bit(X, packed, state)
-                if gathered is not None:
+            def gemm_step():
+                bnb.matmul_4bit(X, packed, state)
+            flops_per_step = 2.0 * M * N * K
+            if not do_gather:
+                modes["main"] = (gemm_step, None)
+            else:
+                # The three curves of SURVEY 8e (+ the row-chunked form), all in one line:
+                #   gemm_only   no exchange: communication-free scaling of the sharded GEMM
+                #   sync        blocking all-gather after every GEMM
+                #   overlapped  async all-gather of step i (RCCL's stream) under the GEMM of step i+1 (two result buffers)
+                #   chunked     inside ONE step: the rank's rows in c chunks, GEMM of chunk i+1 under the gather of chunk i
+                gathered = [torch.empty(M_global, N, dtype=dt, device=dev) for _ in range(2)]
+                pending = [None, None]
+                counter = [0]
+
+                def overlapped_step():
+                    y = bnb.matmul_4bit(X, packed, state)
                     i = counter[0] & 1
                     counter[0] += 1
                     if pending[i] is not None:
                         pending[i].wait()
-                    if args.sync_gather:
-                        dist.all_gather_into_tensor(gathered[i], y)
-                    else:
-                        pending[i] = dist.all_gather_into_tensor(gathered[i], y, async_op=True)
-            flops_per_step = 2.0 * M * N * K
+                    pending[i] = dist.all_gather_into_tensor(gathered[i], y, async_op=True)
+
+                def overlapped_finish():
+                    for i in range(2):
+                        if pending[i] is not None:
+                            pending[i].wait()
+                            pending[i] = None
+
+                def sync_step():
+                    y = bnb.matmul_4bit(X, packed, state)
+                    dist.all_gather_into_tensor(gathered[0], y)
+
+                cg = ChunkedGather(lambda x: bnb.matmul_4bit(x, packed, state), e_row - s_row, N, dt, dev, world,
+                                   chunks=args.chunks)
+                modes["gemm_only"] = (gemm_step, None)
+                modes["sync"] = (sync_step, None)
+                modes["overlapped"] = (overlapped_step, overlapped_finish)
+                modes["chunked"] = (lambda: cg.step(X), cg.finish)
+                modes["main"] = modes["sync"] if args.sync_gather else modes["overlapped"]
     else:
         A = torch.randint(-127, 128, (M, K), generator=g, device=dev, dtype=torch.int8)
         B = torch.randint(-127, 128, (K, N), generator=g, device=dev, dtype=torch.int8)
@@ -325,75 +490,70 @@ def main():
 
         def step():
             bnb.matmul_int8(A, B, sa, sb, torch.float16)
+        modes["main"] = (step, None)
         flops_per_step = 2.0 * M * N * K
 
+    step, finish = modes["main"]
+    prewarm_steps = timer.prewarm(step, finish, args.prewarm_ms) if args.prewarm_ms > 0 else 0
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    if gathered is not None:
-        for w in pending:
-            if w is not None:
-                w.wait()
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    if finish is not None:
+        finish()
+    reps = timer.run(step, finish, args.steps, reps_n)
+    elapsed, ev_ms = median_rep(reps)
     kernel_name = _native.last_kernel()
+    out["prewarm_ms"] = args.prewarm_ms
+    out["prewarm_steps"] = prewarm_steps
+    out["repetitions"] = reps_n
+    out["rep_ms_per_step"] = [round(r[0] / args.steps * 1e3, 5) for r in reps]
 
-    # N > 1 with the gather: a second timed region WITHOUT it (same bracket: barrier + synchronize, max over ranks), so
-    # one run carries both the headline (GEMM + all-gather) and the communication-free scaling of the sharded GEMM
-    gemm_only = None
-    if gathered is not None:
-        torch.cuda.synchronize()
-        dist.barrier()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            bnb.matmul_4bit(X, packed, state)
-        torch.cuda.synchronize()
-        dist.barrier()
-        torch.cuda.synchronize()
-        e2 = time.perf_counter() - t1
-        t = torch.tensor([e2], dtype=torch.float64, device="cpu" if rehearse else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        gemm_only = float(t.item())
+    curves = {}
+    if do_gather:
+        for cname in ("gemm_only", "sync", "overlapped", "chunked"):
+            if modes[cname] is modes["main"]:
+                curves[cname] = (elapsed, ev_ms)
+                continue
+            s_, f_ = modes[cname]
+            for _ in range(max(2, args.warmup)):
+                s_()
+            if f_ is not None:
+                f_()
+            curves[cname] = median_rep(timer.run(s_, f_, args.steps, min(reps_n, 3)))
 
-    # kernel-only launch duration (no gather, no host gaps beyond back-to-back launches)
-    if wl == "nf4_m1":
-        kern_ms = event_time_ms(step, max(1, args.steps // 4)) / 64
-    elif wl == "int8_4096":
-        kern_ms = event_time_ms(step, args.steps)
+    # device-side duration of one launch: the events of the median repetition (for N > 1: of the gather-free curve)
+    if do_gather:
+        kern_ms = curves["gemm_only"][1] / args.steps
+    elif wl == "nf4_m1":
+        kern_ms = ev_ms / args.steps / 64
     else:
-        kern_ms = event_time_ms(lambda: bnb.matmul_4bit(X, packed, state), args.steps)
+        kern_ms = ev_ms / args.steps
 
     ms_per_step = elapsed / args.steps * 1e3
     total_flops = flops_per_step * world
     out["ms_per_step"] = round(ms_per_step, 5)
+    par = f"rows sharded x{world}, weights replicated"
+    if do_gather:
+        par += (", all-gather of outputs (RCCL, blocking)" if args.sync_gather
+                else ", all-gather of outputs (RCCL, async: the gather of step i overlaps the GEMM of step i+1)")
     out["config"] = {"workload": {"nf4_m4096": "Linear4bit-style fused NF4 dequant+matmul, weight 4096x4096 bf16-origin bs64, M=4096 rows per GPU",
                                   "nf4dq_ffn": "fused NF4 + double-quant absmax, weight 11008x4096 bf16 bs64, M=4096",
                                   "int8_4096": "rowwise INT8 matmul_int8 4096x4096x4096 on int8 MFMA",
                                   "nf4_m1": "fused NF4 dequant+GEMV, weight 4096x4096 fp16 bs64, M=1, rotating over 64 layers"}[wl],
-                     "global_rows": M_global, "rows_per_gpu": M, "N": N, "K": K,
-                     "parallelism": f"rows sharded x{world}, weights replicated" + ((", all-gather of outputs (RCCL, blocking)" if args.sync_gather else ", all-gather of outputs (RCCL, async: overlaps the next step's GEMM)") if gathered is not None else ""),
-                     "kernel": kernel_name}
+                     "global_rows": M_global, "rows_per_gpu": M, "N": N, "K": K, "parallelism": par, "kernel": kernel_name}
+    traffic = {}
+    prof = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(prof):
+        try:
+            traffic = json.load(open(prof))
+        except Exception:
+            traffic = {}
     if wl == "nf4_m1":
         gbs = bytes_per_launch / (kern_ms * 1e-3) / 1e9
         out["metric"] = "effective GB/s, fused NF4 dequant+GEMV 4096x4096 M=1 (HBM, 64 rotating layers)"
         out["value"] = round(bytes_per_launch * 64 * world / (elapsed / args.steps) / 1e9, 2)
         out["unit"] = "GB/s"
         out["roofline"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                           "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None,
+                           "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": traffic.get("k_gemv4_bytes_per_launch"),
                            "kernel_us": round(kern_ms * 1e3, 3)}
     else:
         tflops = total_flops / (elapsed / args.steps) / 1e12
@@ -403,13 +563,40 @@ def main():
                          else f"effective TFLOPS, {wl}")
         out["value"] = round(tflops, 2)
         out["unit"] = "TFLOP/s"
-        if gemm_only is not None:
-            out["gemm_only"] = {"value": round(total_flops / (gemm_only / args.steps) / 1e12, 2), "unit": "TFLOP/s",
-                                "ms_per_step": round(gemm_only / args.steps * 1e3, 5),
-                                "note": "same steps without the output all-gather (communication-free scaling of the sharded GEMM)"}
+        for cname, (el, _) in curves.items():
+            out[cname] = {"value": round(total_flops / (el / args.steps) / 1e12, 2), "unit": "TFLOP/s",
+                          "ms_per_step": round(el / args.steps * 1e3, 5)}
+        if do_gather:
+            out["curves_note"] = ("gemm_only = no exchange; sync = blocking all-gather per step; overlapped = async gather of step i "
+                                  f"under the GEMM of step i+1; chunked = {args.chunks} row chunks per step, GEMM of chunk i+1 under "
+                                  "the gather of chunk i (each chunk fills only 1/c of the 256 CUs at this shape)")
+        tkey = {"nf4_m4096": "k_gemm256p_bytes_per_launch", "int8_4096": "k_gemm_i8_bytes_per_launch"}.get(wl)
         out["roofline"] = {"bound": "mfma", "achieved": round(kern_tflops, 2), "peak": peak, "unit": "TFLOP/s",
-                           "frac": round(kern_tflops / peak, 4), "traffic": None,
-                           "kernel_us": round(kern_ms * 1e3, 2)}
+                           "frac": round(kern_tflops / peak, 4), "traffic": traffic.get(tkey) if tkey else None,
+                           "kernel_us": round(kern_ms * 1e3, 2),
+                           "kernel_us_note": "HIP events around the K launches of the median repetition / K (includes the inter-launch boundary)"}
+
+    if args.verify and do_gather:
+        # gathered == unsharded: rank 0 rebuilds every rank's rows and runs the whole batch through the same kernel
+        overlapped_finish()
+        y_local = bnb.matmul_4bit(X, packed, state)
+        full = torch.empty(M_global, N, dtype=dt, device=dev)
+        dist.all_gather_into_tensor(full, y_local)
+        chunked_full = cg.step(X)
+        cg.finish()
+        ok = None
+        if rank == 0:
+            xs = []
+            for r in range(world):
+                gr = torch.Generator(device=dev)
+                gr.manual_seed(4321 + r)
+                sr, er = row_shard(M_global, r, world)
+                xs.append(torch.randn(er - sr, K, generator=gr, device=dev, dtype=torch.float32).to(dt))
+            ref = bnb.matmul_4bit(torch.cat(xs), packed, state)
+            ok = bool(torch.equal(full, ref)) and bool(torch.equal(chunked_full.reshape(M_global, N), ref))
+            del xs, ref
+        out["verified"] = ok
+        del full
 
     if rank == 0 and wl == "nf4_m4096":
         if not args.no_gemv:
@@ -420,8 +607,6 @@ def main():
                 layers.append(bnb.quantize_nf4(Wi, blocksize=64))
                 del Wi
             x1 = torch.randn(1, K, generator=g, device=dev, dtype=torch.float32).to(dt)
-
-            outs = [torch.empty(1, N, dtype=dt, device=dev) for _ in layers]
 
             def gemv_pass():
                 for p, st in layers:
@@ -439,23 +624,23 @@ def main():
                 with torch.cuda.graph(graph, stream=side):
                     gemv_pass()
             torch.cuda.current_stream().wait_stream(side)
-            for _ in range(3):
+            for _ in range(10):
                 graph.replay()
             torch.cuda.synchronize()
-            us = event_time_ms(graph.replay, 20) / 64 * 1e3
-            del outs
+            us = sorted(event_time_ms(graph.replay, 20) for _ in range(5))[2] / 64 * 1e3
             nbytes = N * K // 2 + N * (K // 64) * 4 + K * 2 + N * 2
             gbs = nbytes / (us * 1e-6) / 1e9
-            out["gemv"] = {"workload": "fused NF4 dequant+GEMV 4096x4096 M=1 bf16, 64 rotating layers (605 MB), one HIP graph of 64 launches (per-layer time includes the ~1 us launch boundary)",
+            out["gemv"] = {"workload": "fused NF4 dequant+GEMV 4096x4096 M=1 bf16, 64 rotating layers (605 MB), one HIP graph of 64 launches (per-layer time includes the ~1 us launch boundary); median of 5 x 20 replays",
                            "kernel": _native.last_kernel(), "us_per_layer": round(us, 3), "bytes_per_layer": nbytes,
                            "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                        "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None}}
+                                        "frac": round(gbs / PEAK_HBM_GBS, 4),
+                                        "traffic": traffic.get("k_gemv4_bytes_per_launch")}}
             del layers
         if not args.no_gemv:
             # batch sizes between the two metric shapes (the reference's native path serves M <= 512): one HIP graph of
             # 8 calls per M, same weight; which kernel served it is recorded next to the time
             sweep = []
-            for Ms in (2, 16, 64, 256, 1024):
+            for Ms in (2, 16, 64, 128, 256, 1024):
                 xs_ = torch.randn(Ms, K, generator=g, device=dev, dtype=torch.float32).to(dt)
                 gr = torch.cuda.CUDAGraph()
                 side = torch.cuda.Stream()
@@ -492,15 +677,12 @@ def main():
                     "dtod_copy_gbs_read_plus_write": round(2.0 * (1 << 30) / (copy_ms * 1e-3) / 1e9, 0)}
             except Exception as e:  # context only: never fails the bench
                 out["roofline"]["empirical"] = {"error": str(e)[:200]}
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args, M, N, K, 64, compress, dt)
-    if rank == 0 and wl == "nf4_m4096":
-        prof = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(prof):
-            try:
-                out["roofline"]["traffic"] = json.load(open(prof)).get("k_gemm256p_bytes_per_launch")
-            except Exception:
-                pass
+    if rank == 0 and not args.no_cpu_baseline and world == 1 and wl in ("nf4_m4096", "nf4dq_ffn"):
+        out["cpu_baseline"] = cpu_baseline(args, M, N, K, 64, compress, dt)
+    if rank == 0 and not args.no_cpu_baseline and world == 1 and wl == "nf4_m1":
+        out["cpu_baseline"] = cpu_baseline_gemv(args, N, K, dt)
+    if rank == 0 and not args.no_cpu_baseline and world == 1 and wl == "int8_4096":
+        out["cpu_baseline"] = cpu_baseline_int8(args, M, N, K)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

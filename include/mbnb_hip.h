@@ -12,7 +12,11 @@
  *   - the CALLER allocates everything (outputs and workspaces); the library
  *     never allocates, frees or retains device memory;
  *   - every call is asynchronous on `stream` (no device synchronisation);
- *     the library is re-entrant and holds no mutable global state;
+ *     the library is re-entrant; it keeps no per-call state (workspaces travel as
+ *     arguments) and reads no environment variables.  The only process-wide state is a
+ *     mutex-protected record of which (device, kernel) pairs already had their dynamic-LDS
+ *     limit raised -- an idempotent attribute set once per device, so several devices can be
+ *     driven from one process or from one process each;
  *   - errors are returned as an int status (0 ok, <0 argument error,
  *     >0 hipError_t); no exception crosses the ABI.  mbnb_last_error()
  *     returns a thread-local description of the last failure.
@@ -98,6 +102,13 @@ int mbnb_dequantize_blockwise(const int8_t *q, int64_t numel, const float *absma
 int mbnb_quantize_rowwise(const void *A, int dtype, int64_t rows, int64_t cols, int8_t *out,
                           float *scales, void *stream);
 
+/* dequant_absmax, legacy (non-QuantState) form — functional.py:866-889: codes [rows, num_blocks] with one f32 scale per
+ * `blocksize` codes of a row, scales [rows, dq_blocks]:  out[r, j] = (float)codes[r, j] * scales[r, j / blocksize] for
+ * j < dq_blocks * blocksize, 0 beyond (the reference's zeros_like).  code_kind: 0 int8, 1 uint8, 2 f32.
+ * (The QuantState form of the same function is mbnb_dequantize_blockwise.) */
+int mbnb_dequant_absmax(const void *codes, int code_kind, int64_t rows, int64_t num_blocks, const float *scales,
+                        int64_t dq_blocks, int blocksize, float *out, void *stream);
+
 /* dequantize_rowwise — functional.py:628-636. */
 int mbnb_dequantize_rowwise(const int8_t *q, const float *scales, int64_t rows, int64_t cols,
                             int out_dtype, void *out, void *stream);
@@ -120,8 +131,12 @@ int mbnb_double_quant(const void *A, int dtype, int64_t rows, int64_t cols, int8
  *   packed  u8 [N, K_weight/2]; absmax covers [N, K_weight/blocksize]
  *   K       activation width (= QuantState.shape[1]); K_weight >= K is the padded row length
  *   bias    optional [N] of w_dtype
- * Dispatch: M <= 16 -> wave-per-row GEMV (HBM-bound); larger M -> LDS-tiled MFMA GEMM
- * with the dequant fused in the B-tile producer; odd layouts -> generic kernel.
+ * Dispatch (16-bit weights, blocksize >= 32, 16-byte aligned rows): M = 1 (and M <= 16 when
+ * K % 128 != 0) -> wave-per-row GEMV (HBM-bound); 2 <= M <= 32 (<= 64 for layers of <= 16 Mi
+ * weights) -> weight-streaming skinny MFMA kernel; shapes with >= 96 output tiles of 256 x 256
+ * -> the 256 x 256 LDS-DMA MFMA kernel with the dequant fused into the weight-tile producer;
+ * in between -> 128 x 128 MFMA tiles (split over K when mbnb_matmul_4bit_ws gets a workspace);
+ * fp32 weights, blocksize < 32, K % 8 != 0 -> generic kernel.
  * ------------------------------------------------------------------------- */
 int mbnb_matmul_4bit(const void *A, int64_t M, int64_t K, const uint8_t *packed,
                      const mbnb_absmax *absmax, int64_t N, int64_t K_weight, int blocksize,

@@ -43,6 +43,7 @@ _SIGNATURES = {
                                      c_int, c_void_p, c_void_p]),
     "mbnb_quantize_blockwise": (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mbnb_dequantize_blockwise": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "mbnb_dequant_absmax": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "mbnb_quantize_rowwise": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "mbnb_dequantize_rowwise": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p]),
     "mbnb_double_quant": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -1,8 +1,11 @@
 // api.hip — extern "C" entry points declared in include/mbnb_hip.h: argument validation,
 // status / error-string convention, dispatch to the kernel launchers.  No device allocation,
-// no synchronisation, no mutable global state (thread-local error text only).
+// no synchronisation; the only process-wide state is the per-(device, kernel) record of
+// idempotent function attributes below (mutex-protected), the error text is thread-local.
 #include <cstdarg>
 #include <cstdio>
+#include <mutex>
+#include <unordered_map>
 
 #include "common.h"
 
@@ -19,6 +22,29 @@ void set_error(const char *fmt, ...) {
 }
 void set_kernel_name(const char *name) { g_kernel = name; }
 
+int ensure_dyn_lds(const void *func, int bytes, const char *what) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) {
+        set_error("%s: hipGetDevice failed: %s", what, hipGetErrorString(e));
+        return (int)e;
+    }
+    static std::mutex mu;
+    static std::unordered_map<uint64_t, int> done;   // (kernel, device) -> largest limit set so far
+    const uint64_t key = (reinterpret_cast<uint64_t>(func) << 8) ^ (uint64_t)(dev & 0xFF);
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = done.find(key);
+    if (it != done.end() && it->second >= bytes) return MBNB_OK;
+    e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) {
+        set_error("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d) failed on device %d: %s", what, bytes, dev,
+                  hipGetErrorString(e));
+        return (int)e;
+    }
+    done[key] = bytes;
+    return MBNB_OK;
+}
+
 int check_launch(const char *what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -33,18 +59,17 @@ int quantize_4bit_dispatch(const void *, int, int64_t, int64_t, int64_t, int, in
 int dequantize_4bit_dispatch(const uint8_t *, const AbsmaxView &, int64_t, int64_t, int64_t, int, int, int, void *, hipStream_t);
 int quantize_blockwise_dispatch(const void *, int, int64_t, int, const float *, int8_t *, float *, hipStream_t);
 int dequantize_blockwise_dispatch(const int8_t *, int64_t, const float *, int, int, void *, hipStream_t);
+int dequant_absmax_dispatch(const void *, int, int64_t, int64_t, const float *, int64_t, int, float *, hipStream_t);
 int quantize_rowwise_dispatch(const void *, int, int64_t, int64_t, int8_t *, float *, hipStream_t);
 int dequantize_rowwise_dispatch(const int8_t *, const float *, int64_t, int64_t, int, void *, hipStream_t);
 int double_quant_dispatch(const void *, int, int64_t, int64_t, int8_t *, int8_t *, float *, float *, int, int, hipStream_t);
-int matmul_4bit_dispatch(const void *, int64_t, int64_t, const uint8_t *, const AbsmaxView &, int64_t, int64_t, int, int, int, const void *, int, void *, hipStream_t);
-void set_matmul4_workspace(void *, int64_t);
+int matmul_4bit_dispatch(const void *, int64_t, int64_t, const uint8_t *, const AbsmaxView &, int64_t, int64_t, int, int, int, const void *, int, void *, void *, int64_t, hipStream_t);
 int quantize_fp8_dispatch(const void *, int, int64_t, int64_t, uint8_t *, float *, hipStream_t);
 int dequantize_fp8_dispatch(const uint8_t *, const float *, int64_t, int64_t, int, void *, hipStream_t);
-int linear_fp8_dispatch(const void *, int, int64_t, int64_t, const uint8_t *, const float *, int64_t, const void *, void *, hipStream_t);
-void set_linear8_workspace(void *, int64_t);
+int linear_fp8_dispatch(const void *, int, int64_t, int64_t, const uint8_t *, const float *, int64_t, const void *, void *, void *, int64_t, hipStream_t);
 int64_t matmul4_splitk_slices(int64_t, int64_t, int64_t);
 int matmul_int8_dispatch(const int8_t *, const int8_t *, const float *, const float *, int64_t, int64_t, int64_t, int, void *, void *, hipStream_t);
-int linear_int8_dispatch(const void *, int, int64_t, int64_t, const int8_t *, const float *, int64_t, const void *, void *, hipStream_t);
+int linear_int8_dispatch(const void *, int, int64_t, int64_t, const int8_t *, const float *, int64_t, const void *, void *, void *, int64_t, hipStream_t);
 int embedding_4bit_dispatch(const int64_t *, int64_t, const uint8_t *, const float *, int64_t, int64_t, int, int, int, int64_t, int, void *, hipStream_t);
 int embedding_8bit_dispatch(const int64_t *, int64_t, const int8_t *, const float *, int64_t, int64_t, int, int64_t, int, void *, hipStream_t);
 int outlier_linear_dispatch(const void *, int, int64_t, int64_t, const int8_t *, const float *, int64_t, const int64_t *, int64_t, const void *, const void *, void *, void *, hipStream_t);
@@ -135,6 +160,16 @@ int mbnb_dequantize_blockwise(const int8_t *q, int64_t numel, const float *absma
     return dequantize_blockwise_dispatch(q, numel, absmax, blocksize, out_dtype, out, static_cast<hipStream_t>(stream));
 }
 
+int mbnb_dequant_absmax(const void *codes, int code_kind, int64_t rows, int64_t num_blocks, const float *scales,
+                        int64_t dq_blocks, int blocksize, float *out, void *stream) {
+    if (code_kind < 0 || code_kind > 2) return fail(MBNB_ERR_ARG, "dequant_absmax: code_kind must be 0 (int8), 1 (uint8) or 2 (f32)");
+    if (rows < 0 || num_blocks < 0 || dq_blocks < 0 || blocksize <= 0) return fail(MBNB_ERR_ARG, "dequant_absmax: bad size");
+    if (rows == 0 || num_blocks == 0) return MBNB_OK;
+    if (!codes || !out || (dq_blocks > 0 && !scales)) return fail(MBNB_ERR_ARG, "dequant_absmax: NULL pointer");
+    return dequant_absmax_dispatch(codes, code_kind, rows, num_blocks, scales, dq_blocks, blocksize, out,
+                                   static_cast<hipStream_t>(stream));
+}
+
 int mbnb_quantize_rowwise(const void *A, int dtype, int64_t rows, int64_t cols, int8_t *out, float *scales,
                           void *stream) {
     if (!dtype_ok(dtype)) return fail(MBNB_ERR_ARG, "quantize_rowwise: bad dtype");
@@ -163,9 +198,9 @@ int mbnb_double_quant(const void *A, int dtype, int64_t rows, int64_t cols, int8
                                  static_cast<hipStream_t>(stream));
 }
 
-int mbnb_matmul_4bit(const void *A, int64_t M, int64_t K, const uint8_t *packed, const mbnb_absmax *absmax, int64_t N,
-                     int64_t K_weight, int blocksize, int quant_type, int w_dtype, const void *bias, int out_dtype,
-                     void *out, void *stream) {
+int mbnb_matmul_4bit_ws(const void *A, int64_t M, int64_t K, const uint8_t *packed, const mbnb_absmax *absmax, int64_t N,
+                        int64_t K_weight, int blocksize, int quant_type, int w_dtype, const void *bias, int out_dtype,
+                        void *out, void *workspace, int64_t workspace_bytes, void *stream) {
     if (!dtype_ok(w_dtype) || !dtype_ok(out_dtype) || !qt_ok(quant_type))
         return fail(MBNB_ERR_ARG, "matmul_4bit: bad dtype/quant_type");
     if (M < 0 || N < 0 || K < 0) return fail(MBNB_ERR_ARG, "matmul_4bit: negative size");
@@ -177,24 +212,22 @@ int mbnb_matmul_4bit(const void *A, int64_t M, int64_t K, const uint8_t *packed,
     AbsmaxView v;
     if (int rc = absmax_view(absmax, "matmul_4bit", v)) return rc;
     if (!A || !packed || !out) return fail(MBNB_ERR_ARG, "matmul_4bit: NULL pointer");
+    // the split-K workspace travels down the dispatch as an argument (no per-call state is kept anywhere)
     return matmul_4bit_dispatch(A, M, K, packed, v, N, K_weight, blocksize, quant_type, w_dtype, bias, out_dtype, out,
-                                static_cast<hipStream_t>(stream));
+                                workspace, workspace ? workspace_bytes : 0, static_cast<hipStream_t>(stream));
+}
+
+int mbnb_matmul_4bit(const void *A, int64_t M, int64_t K, const uint8_t *packed, const mbnb_absmax *absmax, int64_t N,
+                     int64_t K_weight, int blocksize, int quant_type, int w_dtype, const void *bias, int out_dtype,
+                     void *out, void *stream) {
+    return mbnb_matmul_4bit_ws(A, M, K, packed, absmax, N, K_weight, blocksize, quant_type, w_dtype, bias, out_dtype, out,
+                               nullptr, 0, stream);
 }
 
 int64_t mbnb_matmul_4bit_workspace_bytes(int64_t M, int64_t N, int64_t K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     const int64_t s = matmul4_splitk_slices(M, N, K);
     return s > 1 ? s * ((M + 127) / 128) * ((N + 127) / 128) * 65536 : 0;   // slices x tiles x 128 x 128 f32
-}
-
-int mbnb_matmul_4bit_ws(const void *A, int64_t M, int64_t K, const uint8_t *packed, const mbnb_absmax *absmax, int64_t N,
-                        int64_t K_weight, int blocksize, int quant_type, int w_dtype, const void *bias, int out_dtype,
-                        void *out, void *workspace, int64_t workspace_bytes, void *stream) {
-    set_matmul4_workspace(workspace, workspace ? workspace_bytes : 0);
-    const int rc = mbnb_matmul_4bit(A, M, K, packed, absmax, N, K_weight, blocksize, quant_type, w_dtype, bias, out_dtype, out,
-                                    stream);
-    set_matmul4_workspace(nullptr, 0);
-    return rc;
 }
 
 int mbnb_matmul_int8(const int8_t *A, const int8_t *B, const float *A_scales, const float *B_scales, int64_t M,
@@ -207,13 +240,19 @@ int mbnb_matmul_int8(const int8_t *A, const int8_t *B, const float *A_scales, co
                                 static_cast<hipStream_t>(stream));
 }
 
-int mbnb_linear_int8(const void *X, int dtype, int64_t M, int64_t K, const int8_t *W, const float *W_scales, int64_t N,
-                     const void *bias, void *out, void *stream) {
+int mbnb_linear_int8_ws(const void *X, int dtype, int64_t M, int64_t K, const int8_t *W, const float *W_scales, int64_t N,
+                        const void *bias, void *out, void *workspace, int64_t workspace_bytes, void *stream) {
     if (!dtype_ok(dtype)) return fail(MBNB_ERR_ARG, "linear_int8: bad dtype");
     if (M < 0 || N < 0 || K < 0) return fail(MBNB_ERR_ARG, "linear_int8: negative size");
     if (M == 0 || N == 0) return MBNB_OK;
     if (!X || !W || !W_scales || !out) return fail(MBNB_ERR_ARG, "linear_int8: NULL pointer");
-    return linear_int8_dispatch(X, dtype, M, K, W, W_scales, N, bias, out, static_cast<hipStream_t>(stream));
+    return linear_int8_dispatch(X, dtype, M, K, W, W_scales, N, bias, out, workspace, workspace ? workspace_bytes : 0,
+                                static_cast<hipStream_t>(stream));
+}
+
+int mbnb_linear_int8(const void *X, int dtype, int64_t M, int64_t K, const int8_t *W, const float *W_scales, int64_t N,
+                     const void *bias, void *out, void *stream) {
+    return mbnb_linear_int8_ws(X, dtype, M, K, W, W_scales, N, bias, out, nullptr, 0, stream);
 }
 
 int mbnb_embedding_4bit(const int64_t *indices, int64_t n_indices, const uint8_t *weight_packed, const float *weight_absmax,
@@ -260,14 +299,6 @@ int mbnb_outlier_linear(const void *X, int dtype, int64_t M, int64_t K, const in
                                    static_cast<hipStream_t>(stream));
 }
 
-int mbnb_linear_int8_ws(const void *X, int dtype, int64_t M, int64_t K, const int8_t *W, const float *W_scales, int64_t N,
-                        const void *bias, void *out, void *workspace, int64_t workspace_bytes, void *stream) {
-    set_linear8_workspace(workspace, workspace ? workspace_bytes : 0);
-    const int rc = mbnb_linear_int8(X, dtype, M, K, W, W_scales, N, bias, out, stream);
-    set_linear8_workspace(nullptr, 0);
-    return rc;
-}
-
 int mbnb_quantize_fp8_e4m3(const void *A, int dtype, int64_t rows, int64_t cols, uint8_t *out, float *scales, void *stream) {
     if (!dtype_ok(dtype)) return fail(MBNB_ERR_ARG, "quantize_fp8_e4m3: bad dtype");
     if (rows < 0 || cols < 0) return fail(MBNB_ERR_ARG, "quantize_fp8_e4m3: negative size");
@@ -291,10 +322,8 @@ int mbnb_linear_fp8(const void *X, int dtype, int64_t M, int64_t K, const uint8_
     if (M < 0 || N < 0 || K < 0) return fail(MBNB_ERR_ARG, "linear_fp8: negative size");
     if (M == 0 || N == 0) return MBNB_OK;
     if (!X || !W || !W_scales || !out) return fail(MBNB_ERR_ARG, "linear_fp8: NULL pointer");
-    set_linear8_workspace(workspace, workspace ? workspace_bytes : 0);
-    const int rc = linear_fp8_dispatch(X, dtype, M, K, W, W_scales, N, bias, out, static_cast<hipStream_t>(stream));
-    set_linear8_workspace(nullptr, 0);
-    return rc;
+    return linear_fp8_dispatch(X, dtype, M, K, W, W_scales, N, bias, out, workspace, workspace ? workspace_bytes : 0,
+                               static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

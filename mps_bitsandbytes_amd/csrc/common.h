@@ -211,5 +211,9 @@ __device__ __forceinline__ float wave_sum(float v) {
 void set_error(const char *fmt, ...);
 void set_kernel_name(const char *name);
 int check_launch(const char *what);
+// Raise a kernel's dynamic-LDS limit (hipFuncAttributeMaxDynamicSharedMemorySize) ONCE per (device, kernel): the
+// attribute belongs to the current device's copy of the function, so the record is kept per device; later calls are
+// one mutex-protected table lookup and never reach the HIP runtime (api.hip).  Returns 0 or a hipError_t.
+int ensure_dyn_lds(const void *func, int bytes, const char *what);
 
 }  // namespace mbnb

@@ -20,11 +20,7 @@ int launch_gemm256q(const T *x, const typename Q4ProducerRT<T, NESTED>::Params &
     }
 #endif
     constexpr int lds = gemm256q_lds_bytes<NESTED>();
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kq), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) {
-        set_error("matmul_4bit: hipFuncSetAttribute(256q) failed: %s", hipGetErrorString(e));
-        return (int)e;
-    }
+    if (int rc = ensure_dyn_lds(reinterpret_cast<const void *>(kq), lds, "matmul_4bit(mfma256q)")) return rc;
     const int64_t tiles = ((M + 255) / 256) * ((N + 255) / 256);
     hipLaunchKernelGGL(kq, dim3((unsigned)tiles), dim3(256), lds, st, x, wp, bias, out, out_dtype, M, N, K);
     return check_launch("matmul_4bit(mfma256q)");

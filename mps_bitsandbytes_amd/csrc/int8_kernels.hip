@@ -420,12 +420,7 @@ int matmul_int8_nt_dispatch(const int8_t *A, const int8_t *Bt, const float *sA, 
 #define MBNB_I8_256(OT)                                                                                              \
     do {                                                                                                             \
         auto kern = k_gemm_i8_256<OT>;                                                                               \
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                     \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds256);                      \
-        if (e != hipSuccess) {                                                                                       \
-            set_error("matmul_int8: hipFuncSetAttribute failed: %s", hipGetErrorString(e));                          \
-            return (int)e;                                                                                           \
-        }                                                                                                            \
+        if (int rc = ensure_dyn_lds(reinterpret_cast<const void *>(kern), lds256, "matmul_int8(mfma256)")) return rc;  \
         hipLaunchKernelGGL(kern, dim3((unsigned)tiles256), dim3(512), lds256, st, A, Bt, sA, sB, static_cast<OT *>(out), M, N, K, epv); \
     } while (0)
         switch (out_dtype) {
@@ -442,12 +437,7 @@ int matmul_int8_nt_dispatch(const int8_t *A, const int8_t *Bt, const float *sA, 
 #define MBNB_I8(OT)                                                                                                  \
     do {                                                                                                             \
         auto kern = k_gemm_i8<OT>;                                                                                   \
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                     \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);                         \
-        if (e != hipSuccess) {                                                                                       \
-            set_error("matmul_int8: hipFuncSetAttribute failed: %s", hipGetErrorString(e));                          \
-            return (int)e;                                                                                           \
-        }                                                                                                            \
+        if (int rc = ensure_dyn_lds(reinterpret_cast<const void *>(kern), lds, "matmul_int8(mfma128)")) return rc;     \
         hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, st, A, Bt, sA, sB, static_cast<OT *>(out), M, N, K); \
     } while (0)
     switch (out_dtype) {
@@ -583,18 +573,11 @@ __global__ __launch_bounds__(1024) void k_skinny8(const T *__restrict__ X, const
     }
 }
 
-// split-K workspace of mbnb_linear_int8_ws for the duration of one call (see matmul4_kernels.hip)
-static thread_local float *tls_ws8 = nullptr;
-static thread_local int64_t tls_ws8_bytes = 0;
-void set_linear8_workspace(void *ws, int64_t bytes) {
-    tls_ws8 = static_cast<float *>(ws);
-    tls_ws8_bytes = bytes;
-}
 int64_t matmul4_splitk_slices(int64_t M, int64_t N, int64_t K);
 
 template <typename T, int WF = W8_INT8>
 static int launch_linear_int8(const void *X, int64_t M, int64_t K, const int8_t *W, const float *scales, int64_t N,
-                              const void *bias, void *out, hipStream_t st) {
+                              const void *bias, void *out, float *ws, int64_t ws_bytes, hipStream_t st) {
     const T *x = static_cast<const T *>(X);
     const T *b = static_cast<const T *>(bias);
     T *o = static_cast<T *>(out);
@@ -621,27 +604,22 @@ static int launch_linear_int8(const void *X, int64_t M, int64_t K, const int8_t 
             typename P::Params wp{W, scales, N, K};
             const int64_t tiles = ((M + 255) / 256) * ((N + 255) / 256);
             const int od = std::is_same<T, f16_t>::value ? MBNB_F16 : MBNB_BF16;
-            static const bool old_w8 = getenv("MBNB_W8_REGSTAGED") != nullptr;   // A/B switch: register-staged k_gemm256
+#ifdef MBNB_ABLATION
+            static const bool old_w8 = getenv("MBNB_W8_REGSTAGED") != nullptr;   // diagnostic builds only: register-staged k_gemm256
+#else
+            constexpr bool old_w8 = false;
+#endif
             if (!old_w8 && ((reinterpret_cast<uintptr_t>(W) & 15) == 0)) {
                 // LDS-DMA pipeline (gemm256w.h): activations and raw int8 weights by global_load_lds
                 auto kw = k_gemm256w<T, WF>;
                 constexpr int ldsw = gemm256w_lds_bytes();
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kw), hipFuncAttributeMaxDynamicSharedMemorySize, ldsw);
-                if (e != hipSuccess) {
-                    set_error("linear_int8: hipFuncSetAttribute(256w) failed: %s", hipGetErrorString(e));
-                    return (int)e;
-                }
+                if (int rc = ensure_dyn_lds(reinterpret_cast<const void *>(kw), ldsw, "linear_int8(mfma256w)")) return rc;
                 hipLaunchKernelGGL(kw, dim3((unsigned)tiles), dim3(512), ldsw, st, x, wp, b, static_cast<void *>(o), od, M, N, K);
                 set_kernel_name(WF == W8_INT8 ? "w8a16_mfma256" : "fp8a16_mfma256");
                 return check_launch("linear_int8(mfma256w)");
             }
             auto kern = k_gemm256<T, P>;
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS);
-            if (e != hipSuccess) {
-                set_error("linear_int8: hipFuncSetAttribute(256) failed: %s", hipGetErrorString(e));
-                return (int)e;
-            }
+            if (int rc = ensure_dyn_lds(reinterpret_cast<const void *>(kern), G256_LDS, "linear_int8(mfma256)")) return rc;
             hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(512), G256_LDS, st, x, wp, b, static_cast<void *>(o), od, M, N, K);
             set_kernel_name(WF == W8_INT8 ? "w8a16_mfma256" : "fp8a16_mfma256");
             return check_launch("linear_int8(mfma256)");
@@ -652,21 +630,16 @@ static int launch_linear_int8(const void *X, int64_t M, int64_t K, const int8_t 
             constexpr int BM = 128, BN = 128;
             constexpr int lds = gemm_decode_lds_bytes<BM, BN>();
             auto kern = k_gemm_decode<T, T, P, BM, BN>;
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            if (e != hipSuccess) {
-                set_error("linear_int8: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-                return (int)e;
-            }
+            if (int rc = ensure_dyn_lds(reinterpret_cast<const void *>(kern), lds, "linear_int8(mfma128)")) return rc;
             const int64_t tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
             const int64_t slices = matmul4_splitk_slices(M, N, K);   // same policy as the 4-bit path
-            if (slices > 1 && tls_ws8 != nullptr && ((reinterpret_cast<uintptr_t>(tls_ws8) & 15) == 0) &&
-                tls_ws8_bytes >= slices * tiles * 65536) {
+            if (slices > 1 && ws != nullptr && ((reinterpret_cast<uintptr_t>(ws) & 15) == 0) &&
+                ws_bytes >= slices * tiles * 65536) {
                 const int64_t kps = (((K / 64) + slices - 1) / slices) * 64;
-                hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)slices), dim3(256), lds, st, x, wp, b, o, M, N, K, tls_ws8, kps);
+                hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)slices), dim3(256), lds, st, x, wp, b, o, M, N, K, ws, kps);
                 int rc = check_launch("linear_int8(mfma128 split-K)");
                 if (rc) return rc;
-                hipLaunchKernelGGL((k_splitk_reduce<T, T>), dim3((unsigned)(tiles * 16)), dim3(256), 0, st, tls_ws8, (int)slices, b, o,
+                hipLaunchKernelGGL((k_splitk_reduce<T, T>), dim3((unsigned)(tiles * 16)), dim3(256), 0, st, ws, (int)slices, b, o,
                                    M, N, (M + BM - 1) / BM, tiles);
                 set_kernel_name(WF == W8_INT8 ? "w8a16_mfma128_splitk" : "fp8a16_mfma128_splitk");
                 return check_launch("linear_int8(split-K reduce)");
@@ -683,22 +656,24 @@ static int launch_linear_int8(const void *X, int64_t M, int64_t K, const int8_t 
 }
 
 int linear_int8_dispatch(const void *X, int dtype, int64_t M, int64_t K, const int8_t *W, const float *scales,
-                         int64_t N, const void *bias, void *out, hipStream_t st) {
+                         int64_t N, const void *bias, void *out, void *workspace, int64_t ws_bytes, hipStream_t st) {
+    float *ws = static_cast<float *>(workspace);
     switch (dtype) {
-        case MBNB_F16: return launch_linear_int8<f16_t>(X, M, K, W, scales, N, bias, out, st);
-        case MBNB_BF16: return launch_linear_int8<bf16_t>(X, M, K, W, scales, N, bias, out, st);
-        default: return launch_linear_int8<float>(X, M, K, W, scales, N, bias, out, st);
+        case MBNB_F16: return launch_linear_int8<f16_t>(X, M, K, W, scales, N, bias, out, ws, ws_bytes, st);
+        case MBNB_BF16: return launch_linear_int8<bf16_t>(X, M, K, W, scales, N, bias, out, ws, ws_bytes, st);
+        default: return launch_linear_int8<float>(X, M, K, W, scales, N, bias, out, ws, ws_bytes, st);
     }
 }
 
 // LinearFP8.forward / matmul_fp8_e4m3 (functional.py:796-807): the same W8A16 kernels with the FP8 byte decoder
 int linear_fp8_dispatch(const void *X, int dtype, int64_t M, int64_t K, const uint8_t *W, const float *scales, int64_t N,
-                        const void *bias, void *out, hipStream_t st) {
+                        const void *bias, void *out, void *workspace, int64_t ws_bytes, hipStream_t st) {
+    float *ws = static_cast<float *>(workspace);
     const int8_t *w = reinterpret_cast<const int8_t *>(W);
     switch (dtype) {
-        case MBNB_F16: return launch_linear_int8<f16_t, W8_FP8>(X, M, K, w, scales, N, bias, out, st);
-        case MBNB_BF16: return launch_linear_int8<bf16_t, W8_FP8>(X, M, K, w, scales, N, bias, out, st);
-        default: return launch_linear_int8<float, W8_FP8>(X, M, K, w, scales, N, bias, out, st);
+        case MBNB_F16: return launch_linear_int8<f16_t, W8_FP8>(X, M, K, w, scales, N, bias, out, ws, ws_bytes, st);
+        case MBNB_BF16: return launch_linear_int8<bf16_t, W8_FP8>(X, M, K, w, scales, N, bias, out, ws, ws_bytes, st);
+        default: return launch_linear_int8<float, W8_FP8>(X, M, K, w, scales, N, bias, out, ws, ws_bytes, st);
     }
 }
 

@@ -415,15 +415,6 @@ static inline int ilog2(int v) {
     return s;
 }
 
-// Split-K workspace handed in by mbnb_matmul_4bit_ws for the duration of one call (thread-local: the library keeps
-// no other per-call state; nullptr = no split-K).
-static thread_local float *tls_ws = nullptr;
-static thread_local int64_t tls_ws_bytes = 0;
-void set_matmul4_workspace(void *ws, int64_t bytes) {
-    tls_ws = static_cast<float *>(ws);
-    tls_ws_bytes = bytes;
-}
-
 // Number of K slices for the 128 x 128 kernel: enough workgroups for two per CU, at least four k-steps (256 k) per
 // slice.  1 = no split.  Shared by the dispatcher and mbnb_matmul_4bit_workspace_bytes.
 int64_t matmul4_splitk_slices(int64_t M, int64_t N, int64_t K) {
@@ -440,7 +431,8 @@ int64_t matmul4_splitk_slices(int64_t M, int64_t N, int64_t K) {
 
 template <typename T, typename OutT, int QT, bool NESTED>
 static int launch_matmul4(const void *A, int64_t M, int64_t K, const uint8_t *packed, const AbsmaxView &am, int64_t N,
-                          int64_t K_weight, int blocksize, const void *bias, void *out, hipStream_t st) {
+                          int64_t K_weight, int blocksize, const void *bias, void *out, float *ws, int64_t ws_bytes,
+                          hipStream_t st) {
     const T *x = static_cast<const T *>(A);
     const T *b = static_cast<const T *>(bias);
     OutT *o = static_cast<OutT *>(out);
@@ -449,9 +441,14 @@ static int launch_matmul4(const void *A, int64_t M, int64_t K, const uint8_t *pa
                              aligned16(packed);
     if constexpr (is16) {
         const int64_t slices = matmul4_splitk_slices(M, N, K);
-        const bool splitk = fast_layout && slices > 1 && tls_ws != nullptr && ((reinterpret_cast<uintptr_t>(tls_ws) & 15) == 0) &&
-                            tls_ws_bytes >= slices * ((M + 127) / 128) * ((N + 127) / 128) * 65536;   // full 128 x 128 f32 tiles
-        static const bool no_skinny = getenv("MBNB_NO_SKINNY") != nullptr;   // debug A/B switch
+        // split-K needs the caller's workspace (mbnb_matmul_4bit_ws): full 128 x 128 f32 tiles per slice
+        const bool splitk = fast_layout && slices > 1 && ws != nullptr && ((reinterpret_cast<uintptr_t>(ws) & 15) == 0) &&
+                            ws_bytes >= slices * ((M + 127) / 128) * ((N + 127) / 128) * 65536;
+#ifdef MBNB_ABLATION
+        static const bool no_skinny = getenv("MBNB_NO_SKINNY") != nullptr;   // diagnostic builds only: A/B switch
+#else
+        constexpr bool no_skinny = false;
+#endif
         // weight-streaming regime with a few activation rows: 2 <= M <= 32, and up to 64 for layers of <= 16 Mi weights
         // (beyond that the activation re-reads of the skinny kernel cost more than split-K's second pass)
         const bool skinny = fast_layout && !no_skinny && M >= 2 && (M <= 32 || (M <= 64 && N * K <= ((int64_t)1 << 24))) &&
@@ -492,12 +489,7 @@ static int launch_matmul4(const void *A, int64_t M, int64_t K, const uint8_t *pa
         constexpr int lds = 16 * NR * MT * 1024;                                                                     \
         auto kern = k_skinny4<T, OutT, QT, NESTED, MT, NR>;                                                          \
         if (lds > 65536) {                                                                                           \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                 \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);                     \
-            if (e != hipSuccess) {                                                                                   \
-                set_error("matmul_4bit: hipFuncSetAttribute(skinny) failed: %s", hipGetErrorString(e));              \
-                return (int)e;                                                                                       \
-            }                                                                                                        \
+            if (int rc = ensure_dyn_lds(reinterpret_cast<const void *>(kern), lds, "matmul_4bit(skinny)")) return rc; \
         }                                                                                                            \
         hipLaunchKernelGGL(kern, dim3((unsigned)((N + 16 * NR - 1) / (16 * NR))), dim3(1024), lds, st, x, packed, am, b, o, M, N, \
                            K, K_weight, sh);                                                                         \
@@ -522,14 +514,19 @@ static int launch_matmul4(const void *A, int64_t M, int64_t K, const uint8_t *pa
             if (bs2_pow2) {
                 using KernT = void (*)(const T *, typename P::Params, const T *, void *, int, int64_t, int64_t, int64_t);
                 // k_gemm256p with the byte-table decode; at blocksize 64 the absmax (plain f32, or int8 codes + absmax2)
-                // is fetched once per four k-steps (AM4).  MBNB_NO_BLUT / MBNB_NO_AM4: A/B switches for those two.
+                // is fetched once per four k-steps (AM4).  Diagnostic builds (-DMBNB_ABLATION) read A/B switches for
+                // those two and for the schedule variants from the environment; the product reads no environment.
+#ifdef MBNB_ABLATION
                 static const bool no_blut = getenv("MBNB_NO_BLUT") != nullptr;
                 static const bool no_am4 = getenv("MBNB_NO_AM4") != nullptr;
+                static const bool use_q = getenv("MBNB_Q4W") != nullptr;   // four-wave variant (gemm256q.h)
+#else
+                constexpr bool no_blut = false, no_am4 = false, use_q = false;
+#endif
                 KernT kern = no_blut ? k_gemm256p<T, NESTED> : k_gemm256p<T, NESTED, 0, false, true>;
                 bool am4 = !no_am4 && blocksize == 64 && (K_weight % 256 == 0);
                 if constexpr (NESTED) am4 = am4 && am.bs2 >= 4 && (reinterpret_cast<uintptr_t>(am.i8) & 3) == 0;
                 if (am4) kern = no_blut ? k_gemm256p<T, NESTED, 0, true> : k_gemm256p<T, NESTED, 0, true, true>;
-                static const bool use_q = getenv("MBNB_Q4W") != nullptr;   // A/B switch: four-wave variant (gemm256q.h)
                 if (use_q && am4 && (int64_t)M * K * (int64_t)sizeof(T) < (1ll << 32) && N * K_weight / 2 < (1ll << 32) &&
                     N * (K_weight / blocksize) < (1ll << 32)) {
                     set_kernel_name("mfma256q");
@@ -557,29 +554,13 @@ static int launch_matmul4(const void *A, int64_t M, int64_t K, const uint8_t *pa
                 }
 #endif
                 constexpr int lds = gemm256p_lds_bytes<NESTED>();
-                {
-                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-                    if (e != hipSuccess) {
-                        set_error("matmul_4bit: hipFuncSetAttribute(256p) failed: %s", hipGetErrorString(e));
-                        return (int)e;
-                    }
-                }
+                if (int rc = ensure_dyn_lds(reinterpret_cast<const void *>(kern), lds, "matmul_4bit(mfma256)")) return rc;
                 hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(512), lds, st, x, wp, b, static_cast<void *>(o), od, M, N, K);
                 set_kernel_name("mfma256");
                 return check_launch("matmul_4bit(mfma256)");
             }
             auto kern = k_gemm256<T, P>;
-            static bool attr_done256 = false;
-            if (!attr_done256) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS);
-                if (e != hipSuccess) {
-                    set_error("matmul_4bit: hipFuncSetAttribute(256) failed: %s", hipGetErrorString(e));
-                    return (int)e;
-                }
-                attr_done256 = true;
-            }
+            if (int rc = ensure_dyn_lds(reinterpret_cast<const void *>(kern), G256_LDS, "matmul_4bit(mfma256)")) return rc;
             hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(512), G256_LDS, st, x, wp, b, static_cast<void *>(o), od, M, N, K);
             set_kernel_name("mfma256");
             return check_launch("matmul_4bit(mfma256)");
@@ -591,23 +572,14 @@ static int launch_matmul4(const void *A, int64_t M, int64_t K, const uint8_t *pa
             const int64_t tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
             constexpr int lds = gemm_decode_lds_bytes<BM, BN>();
             auto kern = k_gemm_decode<T, OutT, P, BM, BN>;
-            static bool attr_done = false;  // benign race: idempotent
-            if (!attr_done) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-                if (e != hipSuccess) {
-                    set_error("matmul_4bit: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-                    return (int)e;
-                }
-                attr_done = true;
-            }
+            if (int rc = ensure_dyn_lds(reinterpret_cast<const void *>(kern), lds, "matmul_4bit(mfma128)")) return rc;
             if (splitk) {
                 // k slices of whole 64-k steps, the last one takes the remainder
                 int64_t kps = (((K / 64) + slices - 1) / slices) * 64;
-                hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)slices), dim3(256), lds, st, x, wp, b, o, M, N, K, tls_ws, kps);
+                hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)slices), dim3(256), lds, st, x, wp, b, o, M, N, K, ws, kps);
                 int rc = check_launch("matmul_4bit(mfma128 split-K)");
                 if (rc) return rc;
-                hipLaunchKernelGGL((k_splitk_reduce<T, OutT>), dim3((unsigned)(tiles * 16)), dim3(256), 0, st, tls_ws, (int)slices,
+                hipLaunchKernelGGL((k_splitk_reduce<T, OutT>), dim3((unsigned)(tiles * 16)), dim3(256), 0, st, ws, (int)slices,
                                    b, o, M, N, (M + BM - 1) / BM, tiles);
                 set_kernel_name("mfma128_splitk");
                 return check_launch("matmul_4bit(split-K reduce)");
@@ -632,23 +604,24 @@ static int launch_matmul4(const void *A, int64_t M, int64_t K, const uint8_t *pa
 
 template <typename T, typename OutT>
 static int matmul4_qt(const void *A, int64_t M, int64_t K, const uint8_t *packed, const AbsmaxView &am, int64_t N,
-                      int64_t K_weight, int blocksize, int qt, const void *bias, void *out, hipStream_t st) {
+                      int64_t K_weight, int blocksize, int qt, const void *bias, void *out, float *ws, int64_t ws_bytes,
+                      hipStream_t st) {
     const bool nested = am.i8 != nullptr;
     if (qt == MBNB_NF4)
-        return nested ? launch_matmul4<T, OutT, MBNB_NF4, true>(A, M, K, packed, am, N, K_weight, blocksize, bias, out, st)
-                      : launch_matmul4<T, OutT, MBNB_NF4, false>(A, M, K, packed, am, N, K_weight, blocksize, bias, out, st);
-    return nested ? launch_matmul4<T, OutT, MBNB_FP4, true>(A, M, K, packed, am, N, K_weight, blocksize, bias, out, st)
-                  : launch_matmul4<T, OutT, MBNB_FP4, false>(A, M, K, packed, am, N, K_weight, blocksize, bias, out, st);
+        return nested ? launch_matmul4<T, OutT, MBNB_NF4, true>(A, M, K, packed, am, N, K_weight, blocksize, bias, out, ws, ws_bytes, st)
+                      : launch_matmul4<T, OutT, MBNB_NF4, false>(A, M, K, packed, am, N, K_weight, blocksize, bias, out, ws, ws_bytes, st);
+    return nested ? launch_matmul4<T, OutT, MBNB_FP4, true>(A, M, K, packed, am, N, K_weight, blocksize, bias, out, ws, ws_bytes, st)
+                  : launch_matmul4<T, OutT, MBNB_FP4, false>(A, M, K, packed, am, N, K_weight, blocksize, bias, out, ws, ws_bytes, st);
 }
 
 template <typename T>
 static int matmul4_out(const void *A, int64_t M, int64_t K, const uint8_t *packed, const AbsmaxView &am, int64_t N,
-                       int64_t K_weight, int blocksize, int qt, const void *bias, int out_dtype, void *out,
-                       hipStream_t st) {
+                       int64_t K_weight, int blocksize, int qt, const void *bias, int out_dtype, void *out, float *ws,
+                       int64_t ws_bytes, hipStream_t st) {
     switch (out_dtype) {
-        case MBNB_F16: return matmul4_qt<T, f16_t>(A, M, K, packed, am, N, K_weight, blocksize, qt, bias, out, st);
-        case MBNB_BF16: return matmul4_qt<T, bf16_t>(A, M, K, packed, am, N, K_weight, blocksize, qt, bias, out, st);
-        default: return matmul4_qt<T, float>(A, M, K, packed, am, N, K_weight, blocksize, qt, bias, out, st);
+        case MBNB_F16: return matmul4_qt<T, f16_t>(A, M, K, packed, am, N, K_weight, blocksize, qt, bias, out, ws, ws_bytes, st);
+        case MBNB_BF16: return matmul4_qt<T, bf16_t>(A, M, K, packed, am, N, K_weight, blocksize, qt, bias, out, ws, ws_bytes, st);
+        default: return matmul4_qt<T, float>(A, M, K, packed, am, N, K_weight, blocksize, qt, bias, out, ws, ws_bytes, st);
     }
 }
 
@@ -660,11 +633,12 @@ extern "C" int mbnb_debug_read_stamps(unsigned long long *host_out) {
 
 int matmul_4bit_dispatch(const void *A, int64_t M, int64_t K, const uint8_t *packed, const AbsmaxView &am, int64_t N,
                          int64_t K_weight, int blocksize, int qt, int w_dtype, const void *bias, int out_dtype,
-                         void *out, hipStream_t st) {
+                         void *out, void *workspace, int64_t ws_bytes, hipStream_t st) {
+    float *ws = static_cast<float *>(workspace);
     switch (w_dtype) {
-        case MBNB_F16: return matmul4_out<f16_t>(A, M, K, packed, am, N, K_weight, blocksize, qt, bias, out_dtype, out, st);
-        case MBNB_BF16: return matmul4_out<bf16_t>(A, M, K, packed, am, N, K_weight, blocksize, qt, bias, out_dtype, out, st);
-        default: return matmul4_out<float>(A, M, K, packed, am, N, K_weight, blocksize, qt, bias, out_dtype, out, st);
+        case MBNB_F16: return matmul4_out<f16_t>(A, M, K, packed, am, N, K_weight, blocksize, qt, bias, out_dtype, out, ws, ws_bytes, st);
+        case MBNB_BF16: return matmul4_out<bf16_t>(A, M, K, packed, am, N, K_weight, blocksize, qt, bias, out_dtype, out, ws, ws_bytes, st);
+        default: return matmul4_out<float>(A, M, K, packed, am, N, K_weight, blocksize, qt, bias, out_dtype, out, ws, ws_bytes, st);
     }
 }
 

@@ -333,6 +333,39 @@ __global__ __launch_bounds__(256) void k_dequantize_blockwise(const int8_t *__re
 }
 
 // =====================================================================================
+// dequant_absmax, legacy form (functional.py:878-889): absmax[r, j] = (float)code[r, j] * scales[r, j / blocksize] for
+// j < dq_blocks * blocksize, 0 beyond (the reference's zeros_like).  QK: 0 int8, 1 uint8, 2 f32 codes.
+// =====================================================================================
+template <int QK>
+__global__ __launch_bounds__(256) void k_dequant_absmax(const void *__restrict__ q, int64_t rows, int64_t num_blocks,
+                                                       const float *__restrict__ scales, int64_t dq_blocks, int blocksize,
+                                                       float *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * num_blocks) return;
+    const int64_t r = i / num_blocks, j = i - r * num_blocks, dqb = j / blocksize;
+    float v = 0.0f;
+    if (dqb < dq_blocks) {
+        float c;
+        if constexpr (QK == 0) c = (float)static_cast<const int8_t *>(q)[i];
+        else if constexpr (QK == 1) c = (float)static_cast<const uint8_t *>(q)[i];
+        else c = static_cast<const float *>(q)[i];
+        v = c * scales[r * dq_blocks + dqb];
+    }
+    out[i] = v;
+}
+
+int dequant_absmax_dispatch(const void *q, int q_kind, int64_t rows, int64_t num_blocks, const float *scales,
+                            int64_t dq_blocks, int blocksize, float *out, hipStream_t st) {
+    const unsigned grid = (unsigned)((rows * num_blocks + 255) / 256);
+    switch (q_kind) {
+        case 0: hipLaunchKernelGGL(k_dequant_absmax<0>, dim3(grid), dim3(256), 0, st, q, rows, num_blocks, scales, dq_blocks, blocksize, out); break;
+        case 1: hipLaunchKernelGGL(k_dequant_absmax<1>, dim3(grid), dim3(256), 0, st, q, rows, num_blocks, scales, dq_blocks, blocksize, out); break;
+        default: hipLaunchKernelGGL(k_dequant_absmax<2>, dim3(grid), dim3(256), 0, st, q, rows, num_blocks, scales, dq_blocks, blocksize, out); break;
+    }
+    return check_launch("dequant_absmax");
+}
+
+// =====================================================================================
 // quantize_rowwise: one workgroup per row (pass 1 absmax, pass 2 quantise; the row stays in L2)
 // =====================================================================================
 template <typename T>

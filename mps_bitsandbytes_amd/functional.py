@@ -128,17 +128,46 @@ def _absmax_desc(absmax: Tensor, state2: Optional[QuantState], keep: list) -> Ab
     (QuantState.state2 as produced by quantize_4bit, functional.py:288-292) is decoded inside the
     consuming kernel; anything else is first brought to plain f32 by dequantize_blockwise.
     `keep` collects tensors that must stay alive until the launch has been enqueued."""
+    if absmax.device.type != 'cuda':
+        raise ValueError(f"absmax must live on a 'cuda' (ROCm/HIP) device before a kernel launch, got '{absmax.device}'")
     if state2 is not None:
         if (absmax.dtype == torch.int8 and state2.state2 is None and state2.dtype == torch.float32
                 and state2.absmax.dtype == torch.float32):
+            bs2 = int(state2.blocksize)
             q = absmax.contiguous()
-            a2 = state2.absmax.contiguous()
+            # the second-level absmax follows the first level's device (a QuantState built by from_dict() defaults to
+            # 'cpu'; handing the kernel a host pointer would be a GPU fault where the reference raises a device mismatch)
+            a2 = state2.absmax.to(device=absmax.device, dtype=torch.float32).contiguous()
+            need2 = (q.numel() + bs2 - 1) // bs2 if bs2 > 0 else -1
+            if bs2 <= 0 or a2.numel() < need2:
+                raise ValueError(f"state2.absmax has {a2.numel()} elements, expected {need2} "
+                                 f"({q.numel()} absmax codes in blocks of {bs2})")
             keep += [q, a2]
-            return AbsmaxDesc(None, q.data_ptr(), a2.data_ptr(), int(state2.blocksize))
+            return AbsmaxDesc(None, q.data_ptr(), a2.data_ptr(), bs2)
+        state2 = _state_on(state2, absmax.device)
         absmax = dequantize_blockwise(absmax, state2)
     a = absmax.to(torch.float32).contiguous()
     keep.append(a)
     return AbsmaxDesc(a.data_ptr(), None, None, 0)
+
+
+def _state_on(state: QuantState, device) -> QuantState:
+    """A copy of `state` (recursively) whose tensors live on `device`; the caller's object is left untouched."""
+    if state.absmax.device == device and (state.state2 is None or state.state2.absmax.device == device):
+        return state
+    return QuantState(absmax=state.absmax.to(device), shape=state.shape, code=state.code, blocksize=state.blocksize,
+                      quant_type=state.quant_type, dtype=state.dtype, offset=state.offset,
+                      state2=None if state.state2 is None else _state_on(state.state2, device))
+
+
+def _check_absmax_count(absmax: Tensor, rows: int, cols_padded: int, blocksize: int, what: str) -> None:
+    """The kernels index absmax as [rows, cols_padded / blocksize] and receive no length: a checkpoint whose blocksize or
+    shape disagrees with its absmax must fail here (the reference's absmax.view(N, num_blocks_per_row) raises,
+    functional.py:371-373), not read past the allocation."""
+    need = rows * (cols_padded // blocksize)
+    if absmax.numel() != need:
+        raise ValueError(f"{what}: absmax has {absmax.numel()} elements, expected {need} "
+                         f"({rows} rows x {cols_padded // blocksize} blocks of {blocksize})")
 
 
 # ============================================================================= 4-bit
@@ -273,6 +302,7 @@ def dequantize_4bit(
     if A.numel() * 2 < rows * cols_padded or cols > cols_padded:
         raise ValueError(
             f"packed tensor has {A.numel()} bytes but absmax/shape describe {rows * cols_padded} 4-bit values")
+    _check_absmax_count(absmax, rows, cols_padded, blocksize, "dequantize_4bit")
 
     keep: list = []
     desc = _absmax_desc(absmax.to(A.device), state2, keep)
@@ -481,6 +511,7 @@ def matmul_4bit(
         packed = packed.to(torch.uint8)
     if packed.numel() * 2 < N * K_weight:
         raise ValueError(f"packed weight has {packed.numel()} bytes, expected {N * K_weight // 2}")
+    _check_absmax_count(quant_state.absmax, N, K_weight, blocksize, "matmul_4bit")
 
     out_dtype = compute_dtype if compute_dtype in _native.DTYPE_CODE else w_dtype
     out = torch.empty(M, N, dtype=out_dtype, device=A.device)
@@ -763,8 +794,25 @@ def double_quant(
 
 def dequant_absmax(absmax_quant: Tensor, absmax_scales, blocksize: int = 256) -> Tensor:
     """Dequantize double-quantized absmax values (reference: functional.py:866-889).
-    Only the live form (a QuantState in `absmax_scales`) is supported; the legacy per-row
-    uint8 form is unreachable from Linear4bit."""
+
+    `absmax_scales` a QuantState: dequantize_blockwise (the live form, functional.py:870-871).  Otherwise the legacy
+    form (functional.py:873-889): codes [rows, num_blocks] (or 1-D) with one scale per `blocksize` codes of a row;
+    returns f32 ``codes.float() * scale``, zero where no scale block covers a code (the reference's zeros_like)."""
     if isinstance(absmax_scales, QuantState):
         return dequantize_blockwise(absmax_quant, absmax_scales)
-    raise NotImplementedError("dequant_absmax: only the QuantState form is supported on this backend")
+    _check_device(absmax_quant, "dequant_absmax")
+    q = absmax_quant.contiguous()
+    rows = q.shape[0] if q.dim() > 1 else 1
+    num_blocks = q.numel() // rows if rows > 0 else q.numel()
+    scales = absmax_scales.to(device=q.device, dtype=torch.float32).contiguous()
+    dq_blocks = scales.numel() // rows if rows > 0 else scales.numel()
+    if blocksize <= 0:
+        raise ValueError(f"blocksize must be positive, got {blocksize}")
+    kind = 0 if q.dtype == torch.int8 else 1 if q.dtype == torch.uint8 else 2
+    if kind == 2 and q.dtype != torch.float32:
+        q = q.float()       # the reference's `.float()` of the codes
+    out = torch.empty(q.shape, dtype=torch.float32, device=q.device)
+    with torch.cuda.device(q.device):
+        check(_native.lib().mbnb_dequant_absmax(ptr(q), kind, rows, num_blocks, ptr(scales), dq_blocks, int(blocksize),
+                                                ptr(out), stream_ptr(q.device)), "dequant_absmax")
+    return out

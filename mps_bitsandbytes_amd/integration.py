@@ -56,8 +56,15 @@ class BitsAndBytesConfig:
         d = dict(config_dict)
         dt = d.get('bnb_4bit_compute_dtype')
         if isinstance(dt, str):
-            # 'torch.bfloat16' contains 'float16': test the longer name first
-            d['bnb_4bit_compute_dtype'] = torch.bfloat16 if 'bfloat16' in dt else torch.float16
+            # Reproduces the reference exactly (integration.py:86-92): it tests 'float16' first, and 'torch.bfloat16'
+            # CONTAINS 'float16' -- so every string, 'torch.bfloat16' included, comes back as torch.float16 there.
+            # A torch.dtype value passes through unchanged.  (INTEGRATION.md §4 lists this as a reference quirk kept.)
+            if 'float16' in dt:
+                d['bnb_4bit_compute_dtype'] = torch.float16
+            elif 'bfloat16' in dt:
+                d['bnb_4bit_compute_dtype'] = torch.bfloat16
+            else:
+                d['bnb_4bit_compute_dtype'] = torch.float16
         return cls(**{k: v for k, v in d.items() if k in cls.__dataclass_fields__})
 
     @property

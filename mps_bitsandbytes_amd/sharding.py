@@ -51,3 +51,44 @@ def sharded_linear(local_rows: torch.Tensor, forward: Callable[[torch.Tensor], t
             s, e = row_shard(M_global, r, world)
             out[s:e] = staged[r * max_rows: r * max_rows + (e - s)]
     return out
+
+
+class ChunkedGather:
+    """Row-chunked overlap of the output all-gather INSIDE one step (third curve).
+
+    The rank's `rows` rows are cut into `chunks` contiguous chunks.  Chunk i is pushed through `forward` on the
+    caller's stream and handed to an asynchronous `all_gather_into_tensor`, so the collective of chunk i (RCCL's own
+    stream on GPUs) runs under the GEMM of chunk i + 1; only the last chunk's gather is exposed.  Every collective
+    stays one contiguous [world, rows/c, N] slab; the result buffer is laid out [chunk][rank][row-in-chunk][N] and
+    returned as a strided VIEW in global row order (rank, chunk, row) -- `.reshape(M_global, N)` materialises it.
+    Two result buffers alternate between steps: a buffer is rewritten only after the gathers that filled it two steps
+    earlier were waited for.  `rows` must be divisible by `chunks` (equal shards; ragged batches use sharded_linear)."""
+
+    def __init__(self, forward: Callable[[torch.Tensor], torch.Tensor], rows: int, N: int, dtype: torch.dtype, device,
+                 world_size: int, chunks: int = 2, group: Optional[dist.ProcessGroup] = None):
+        if chunks < 1 or rows % chunks != 0:
+            raise ValueError(f"ChunkedGather: {rows} rows are not divisible into {chunks} chunks")
+        self.forward, self.rows, self.N, self.world, self.chunks, self.group = forward, rows, N, world_size, chunks, group
+        self.rc = rows // chunks
+        self.buffers = [torch.empty(chunks, world_size, self.rc, N, dtype=dtype, device=device) for _ in range(2)]
+        self.pending = [[], []]
+        self.count = 0
+
+    def step(self, local_rows: torch.Tensor) -> torch.Tensor:
+        b = self.count & 1
+        self.count += 1
+        for w in self.pending[b]:
+            w.wait()
+        self.pending[b] = []
+        buf = self.buffers[b]
+        for i in range(self.chunks):
+            y = self.forward(local_rows[i * self.rc:(i + 1) * self.rc])
+            self.pending[b].append(dist.all_gather_into_tensor(buf[i].view(self.world * self.rc, self.N), y.contiguous(),
+                                                               group=self.group, async_op=True))
+        return buf.permute(1, 0, 2, 3)   # [rank][chunk][row][N]: global row order; valid after finish()
+
+    def finish(self) -> None:
+        for b in range(2):
+            for w in self.pending[b]:
+                w.wait()
+            self.pending[b] = []

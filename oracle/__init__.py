@@ -42,7 +42,7 @@ def lib():
         build()
         _lib = ctypes.CDLL(_LIB_PATH)
         for name in ("orc_quantize_4bit", "orc_dequantize_4bit", "orc_quantize_blockwise",
-                     "orc_dequantize_blockwise", "orc_quantize_rowwise", "orc_dequantize_rowwise",
+                     "orc_dequantize_blockwise", "orc_dequant_absmax", "orc_quantize_rowwise", "orc_dequantize_rowwise",
                      "orc_double_quant", "orc_matmul_4bit", "orc_matmul_int8", "orc_linear_int8",
                      "orc_embedding_4bit", "orc_embedding_8bit", "orc_outlier_linear",
                      "orc_quantize_fp8_e4m3", "orc_dequantize_fp8_e4m3", "orc_linear_fp8"):
@@ -149,6 +149,21 @@ def dequantize_blockwise(q: torch.Tensor, absmax: torch.Tensor, blocksize: int =
 
 
 # --------------------------------------------------------------------------- rowwise int8
+def dequant_absmax(absmax_quant: torch.Tensor, absmax_scales: torch.Tensor, blocksize: int = 256) -> torch.Tensor:
+    """functional.py:866-889, legacy form (codes [rows, num_blocks] or [num_blocks], one scale per `blocksize` codes)."""
+    q = absmax_quant.contiguous()
+    rows = q.shape[0] if q.dim() > 1 else 1
+    num_blocks = q.numel() // rows if rows > 0 else q.numel()
+    dq_blocks = absmax_scales.numel() // rows if rows > 0 else absmax_scales.numel()
+    kind = 0 if q.dtype == torch.int8 else 1 if q.dtype == torch.uint8 else 2
+    if kind == 2:
+        q = q.float()
+    out = torch.empty(q.shape, dtype=torch.float32)
+    _chk(lib().orc_dequant_absmax(_p(q), kind, _i64(rows), _i64(num_blocks), _p(absmax_scales.float().contiguous()),
+                                  _i64(dq_blocks), int(blocksize), _p(out)), "dequant_absmax")
+    return out
+
+
 def quantize_rowwise(t: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     """functional.py:607-625."""
     t = t.contiguous()

@@ -261,6 +261,31 @@ int orc_dequantize_blockwise(const int8_t *q, int64_t numel, const float *absmax
 }
 
 /* ---------------------------------------------------------------------------
+ * dequant_absmax, legacy (non-QuantState) form — functional.py:878-889.
+ *   absmax = zeros(rows, num_blocks) f32;  for dqb < dq_blocks:
+ *     absmax[:, dqb*bs : min((dqb+1)*bs, num_blocks)] = q[:, ...].float() * scales[:, dqb]
+ * Codes past dq_blocks * blocksize keep the zero of zeros_like.  q_kind: 0 int8, 1 uint8, 2 f32
+ * (any other code dtype is `.float()`-ed by the caller, which is what the reference does).
+ * ------------------------------------------------------------------------- */
+int orc_dequant_absmax(const void *q, int q_kind, int64_t rows, int64_t num_blocks, const float *scales,
+                       int64_t dq_blocks, int blocksize, float *out) {
+    if (blocksize <= 0 || rows < 0 || num_blocks < 0 || dq_blocks < 0) return -1;
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < rows; r++)
+        for (int64_t j = 0; j < num_blocks; j++) {
+            const int64_t i = r * num_blocks + j, dqb = j / blocksize;
+            float v = 0.0f;
+            if (dqb < dq_blocks) {
+                float c = q_kind == 0 ? (float)((const int8_t *)q)[i] : q_kind == 1 ? (float)((const uint8_t *)q)[i]
+                                                                                    : ((const float *)q)[i];
+                v = c * scales[r * dq_blocks + dqb];
+            }
+            out[i] = v;
+        }
+    return 0;
+}
+
+/* ---------------------------------------------------------------------------
  * quantize_rowwise — functional.py:607-625.
  *   scales = max|x| per row (f32) clamp 1e-8 — the absmax itself  (:617-618)
  *   q = clamp(round(x * (127.0/scales)), -127, 127)              (:620-623)

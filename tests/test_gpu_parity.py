@@ -604,3 +604,164 @@ def test_matmul_mfma256_four_wave_variant(tmp_path):
         assert got["p"][idx][0] == "mfma256" and got["q"][idx][0] == "mfma256q", (got["p"][idx][0], got["q"][idx][0])
         a, b = got["p"][idx][1], got["q"][idx][1]
         assert a.dtype == b.dtype and torch.equal(a.view(torch.uint8), b.view(torch.uint8)), f"case {cases[idx]} differs"
+
+
+# --------------------------------------------------------------------------- round-2 additions: benched instantiation, config[4]
+def test_matmul_benched_instantiation_bf16_plain_full_size():
+    """The exact instantiation bench.py times (BASELINE metric): k_gemm256p<bf16, plain f32 absmax, absmax-by-4, byte
+    table> at M = N = K = 4096 -- 64 k-steps, i.e. 16 rotations of the absmax-by-4 slots and 32 of the stage parity
+    (the K = 256 cases above see a single rotation).  Row-sample parity vs the oracle: one row in every 256-row tile at a
+    different in-tile position, the first rows, the last rows, and random ones; every column of those rows."""
+    N = K = M = 4096
+    W = synthetic.normal((N, K), torch.bfloat16, seed=1234)
+    packed, st = bnb.quantize_nf4(W.to(DEV))
+    op, oa, _ = oracle.quantize_4bit(W, 64, "nf4")
+    assert torch.equal(packed.cpu(), op) and torch.equal(st.absmax.cpu(), oa)
+    X = synthetic.normal((M, K), torch.bfloat16, seed=4321).to(DEV)
+    Y = bnb.matmul_4bit(X, packed, st)
+    assert _native.last_kernel() == "mfma256"
+    assert Y.dtype == torch.bfloat16 and torch.isfinite(Y).all()
+    rows = sorted(set([t * 256 + (37 * t + 5) % 256 for t in range(16)] + list(range(8)) + [M - 1, M - 2, M - 33] +
+                      [int(v) for v in synthetic.uniform_u64(24, 19) % np.uint64(M)]))
+    rows_t = torch.tensor(rows)
+    y_ref = oracle.matmul_4bit(X[rows_t.to(DEV)].cpu(), op, oa, (N, K), 64, "nf4", torch.bfloat16)
+    err = rel_fro(Y[rows_t.to(DEV)], y_ref)
+    assert err <= TOL[torch.bfloat16], f"benched instantiation: row-sample rel-err {err:.3e}"
+    # element-wise as well: no single output may be off by more than a few bf16 ulps of the row scale
+    diff = (Y[rows_t.to(DEV)].float().cpu() - y_ref.float()).abs().max().item()
+    assert diff <= 4e-2 * y_ref.float().abs().max().item()
+    assert torch.equal(Y, bnb.matmul_4bit(X, packed, st)), "mfma256 is not run-to-run deterministic"
+    # bias through the LDS-staged epilogue of the same instantiation
+    bias = synthetic.normal((N,), torch.bfloat16, seed=77)
+    Yb = bnb.matmul_4bit(X, packed, st, bias.to(DEV))
+    yb_ref = oracle.matmul_4bit(X[rows_t.to(DEV)].cpu(), op, oa, (N, K), 64, "nf4", torch.bfloat16, bias)
+    assert rel_fro(Yb[rows_t.to(DEV)], yb_ref) <= TOL[torch.bfloat16]
+
+
+def test_matmul_config4_global_shape_on_one_gpu():
+    """BASELINE configs[4]: global batch M = 32768 on the 4096 x 4096 NF4 weight (bf16).  On one GPU the whole batch is
+    one launch of 128 x 16 tiles (64-bit row offsets, 2048 workgroups = 8 per CU); row-sample parity vs the oracle, and
+    each of the 8 row shards computed on its own equals its slice of the unsharded result bit for bit (what the 8-way
+    sharded run gathers)."""
+    from mps_bitsandbytes_amd.sharding import row_shard
+    M, N, K = 32768, 4096, 4096
+    W = synthetic.normal((N, K), torch.bfloat16, seed=1234)
+    packed, st = bnb.quantize_nf4(W.to(DEV))
+    op, oa, _ = oracle.quantize_4bit(W, 64, "nf4")
+    g = torch.Generator(device=DEV)
+    g.manual_seed(99)
+    X = torch.randn(M, K, generator=g, device=DEV, dtype=torch.float32).to(torch.bfloat16)
+    Y = bnb.matmul_4bit(X, packed, st)
+    assert _native.last_kernel() == "mfma256" and Y.shape == (M, N)
+    assert torch.isfinite(Y).all()
+    rows = sorted(set([t * 2048 + (611 * t + 3) % 2048 for t in range(16)] + [0, 1, 255, 256, M - 257, M - 256, M - 1] +
+                      [int(v) for v in synthetic.uniform_u64(16, 23) % np.uint64(M)]))
+    rows_t = torch.tensor(rows)
+    y_ref = oracle.matmul_4bit(X[rows_t.to(DEV)].cpu(), op, oa, (N, K), 64, "nf4", torch.bfloat16)
+    err = rel_fro(Y[rows_t.to(DEV)], y_ref)
+    assert err <= TOL[torch.bfloat16], f"M=32768 row-sample rel-err {err:.3e}"
+    for r in range(8):
+        s, e = row_shard(M, r, 8)
+        assert torch.equal(bnb.matmul_4bit(X[s:e], packed, st), Y[s:e]), f"shard {r} differs from the unsharded result"
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two visible GPUs")
+def test_second_device_from_the_same_process():
+    """One process, two devices: every kernel family that raises its dynamic-LDS limit (a per-device function attribute)
+    is first used on cuda:0 and then on cuda:1 -- results must match bit for bit (SURVEY 8b threading / streams)."""
+    d0, d1 = torch.device("cuda:0"), torch.device("cuda:1")
+    W = synthetic.normal((2560, 512), torch.bfloat16, seed=5)
+    for M in (1, 24, 200, 2560):        # gemv, skinny, 128^2 (+ split-K), 256^2
+        X = synthetic.normal((M, 512), torch.bfloat16, seed=6 + M)
+        outs, kerns = [], []
+        for d in (d0, d1):
+            packed, st = bnb.quantize_nf4(W.to(d))
+            outs.append(bnb.matmul_4bit(X.to(d), packed, st).cpu())
+            kerns.append(_native.last_kernel())
+        assert kerns[0] == kerns[1]
+        assert torch.equal(outs[0], outs[1]), f"M={M} ({kerns[0]}): cuda:1 differs from cuda:0"
+    A = torch.randint(-127, 128, (2560, 512), dtype=torch.int8)
+    B = torch.randint(-127, 128, (512, 2560), dtype=torch.int8)
+    sa, sb = torch.rand(2560) + 0.5, torch.rand(2560) + 0.5
+    o = [bnb.matmul_int8(A.to(d), B.to(d), sa.to(d), sb.to(d), torch.float16).cpu() for d in (d0, d1)]
+    assert torch.equal(o[0], o[1])
+
+
+def test_bench_gpus_flag_spawns_ranks_and_gathers_the_unsharded_result():
+    """`python bench.py --gpus 2` without a launcher starts 2 child ranks (here: BENCH_REHEARSE=1 -> both on cuda:0 over
+    gloo), reports n_gpus = 2, and the gathered output of the HIP path equals the unsharded result (--verify)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env["BENCH_REHEARSE"] = "1"
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--reps", "2", "--prewarm-ms", "0", "--no-cpu-baseline", "--no-gemv", "--no-empirical", "--verify"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 2 and rec["verified"] is True
+    assert rec["config"]["global_rows"] == 8192 and rec["config"]["kernel"] == "mfma256"
+    for curve in ("gemm_only", "sync", "overlapped", "chunked"):
+        assert rec[curve]["value"] > 0
+
+
+def test_dequant_absmax_legacy_form_bit_exact():
+    """functional.py:866-889, the non-QuantState form, against the reference's outputs (g8_misc.npz) and the oracle."""
+    import json
+    import os
+    from tests.goldenio import HERE
+    from tests.test_oracle_misc_golden import load_case
+    man = json.load(open(os.path.join(HERE, "manifest_misc.json")))
+    npz = np.load(os.path.join(HERE, "g8_misc.npz"))
+    for c in man["dequant_absmax"]:
+        q, scales, want = load_case(npz, c)
+        got = bnb.dequant_absmax(q.to(DEV), scales.to(DEV), blocksize=c["blocksize"])
+        assert got.dtype == torch.float32 and got.shape == want.shape
+        assert bits_equal(got.cpu(), want), c
+    # the QuantState form still routes to dequantize_blockwise
+    x = synthetic.normal((1000,), torch.float32, seed=3).to(DEV)
+    qb, stb = bnb.quantize_blockwise(x, blocksize=256)
+    assert torch.equal(bnb.dequant_absmax(qb, stb), bnb.dequantize_blockwise(qb, stb))
+    # a larger random case vs the oracle
+    g = torch.Generator().manual_seed(5)
+    q = torch.randint(0, 256, (37, 1111), generator=g, dtype=torch.uint8)
+    sc = torch.rand(37, 5, generator=g) + 0.1
+    assert bits_equal(bnb.dequant_absmax(q.to(DEV), sc.to(DEV), 256).cpu(), oracle.dequant_absmax(q, sc, 256))
+
+
+def test_quant_state_from_dict_with_cpu_state2_and_mismatched_absmax():
+    """QuantState.from_dict() defaults to 'cpu'; the nested absmax2 must follow the packed weight's device
+    (never a host pointer into a kernel), and an absmax that does not match shape / blocksize must raise on the host."""
+    N, K = 256, 512
+    W = synthetic.normal((N, K), torch.float16, seed=91)
+    packed, st = bnb.quantize_nf4(W.to(DEV), compress_statistics=True)
+    X = synthetic.normal((8, K), torch.float16, seed=92).to(DEV)
+    want = bnb.matmul_4bit(X, packed, st)
+    st_cpu = QuantState.from_dict({k: (v.cpu() if torch.is_tensor(v) else v) for k, v in st.as_dict().items()
+                                   if k != "state2"} | {"state2": {k: (v.cpu() if torch.is_tensor(v) else v)
+                                                                    for k, v in st.state2.as_dict().items()}})
+    assert st_cpu.absmax.device.type == "cpu" and st_cpu.state2.absmax.device.type == "cpu"
+    assert torch.equal(bnb.matmul_4bit(X, packed, st_cpu), want)
+    assert torch.equal(bnb.dequantize_4bit(packed, st_cpu), bnb.dequantize_4bit(packed, st))
+    # first level on the GPU, second level left on the host: moved, not dereferenced
+    st_mixed = QuantState(absmax=st.absmax, shape=st.shape, blocksize=64, quant_type="nf4", dtype=torch.float16,
+                          state2=QuantState(absmax=st.state2.absmax.cpu(), shape=st.state2.shape, blocksize=256,
+                                            quant_type="int8", dtype=torch.float32))
+    assert torch.equal(bnb.matmul_4bit(X, packed, st_mixed), want)
+    # a checkpoint whose blocksize disagrees with its absmax
+    bad = QuantState(absmax=st.absmax, shape=st.shape, blocksize=32, quant_type="nf4", dtype=torch.float16, state2=st.state2)
+    with pytest.raises(ValueError, match="absmax has"):
+        bnb.matmul_4bit(X, packed, bad)
+    with pytest.raises(ValueError, match="absmax has"):
+        bnb.dequantize_4bit(packed, bad)
+    short2 = QuantState(absmax=st.absmax, shape=st.shape, blocksize=64, quant_type="nf4", dtype=torch.float16,
+                        state2=QuantState(absmax=st.state2.absmax[:1], shape=st.state2.shape, blocksize=256,
+                                          quant_type="int8", dtype=torch.float32))
+    with pytest.raises(ValueError, match="state2.absmax has"):
+        bnb.matmul_4bit(X, packed, short2)

@@ -132,7 +132,12 @@ def test_bitsandbytes_config_mirrors_reference():
     assert sorted(d) == ["bnb_4bit_compute_dtype", "bnb_4bit_quant_type", "bnb_4bit_use_double_quant", "llm_int8_skip_modules",
                          "llm_int8_threshold", "load_in_4bit", "load_in_8bit"]
     back = bnb.BitsAndBytesConfig.from_dict(d)
-    assert back.bnb_4bit_compute_dtype == torch.bfloat16 and back.bnb_4bit_quant_type == "fp4" and back.load_in_4bit
+    # the reference's string parse tests 'float16' first and 'torch.bfloat16' contains it (reference integration.py:86-92):
+    # the string round trip lands on float16 there, and therefore here; a torch.dtype value passes through
+    assert back.bnb_4bit_compute_dtype == torch.float16 and back.bnb_4bit_quant_type == "fp4" and back.load_in_4bit
+    d2 = dict(d, bnb_4bit_compute_dtype=torch.bfloat16)
+    assert bnb.BitsAndBytesConfig.from_dict(d2).bnb_4bit_compute_dtype == torch.bfloat16
+    assert bnb.BitsAndBytesConfig.from_dict(dict(d, bnb_4bit_compute_dtype="float32")).bnb_4bit_compute_dtype == torch.float16
     assert bnb.BitsAndBytesConfig().quantization_method == "none"
     with pytest.raises(ValueError, match="both 4-bit and 8-bit"):
         bnb.BitsAndBytesConfig(load_in_4bit=True, load_in_8bit=True)
@@ -183,3 +188,15 @@ def test_linear_fp8_module_mirrors_reference_without_a_gpu():
                lambda: bnb.LinearFP8.from_linear(torch.nn.Linear(64, 8).half())):
         with pytest.raises(ValueError, match="requires tensor on a 'cuda'"):
             fn()
+
+
+def test_absmax_descriptor_never_hands_the_kernels_a_host_pointer_or_a_short_absmax():
+    """the C ABI receives no lengths and dereferences what it is given; the host mirror must stop a CPU-resident
+    absmax and an absmax whose count disagrees with shape/blocksize BEFORE any launch (the reference raises from
+    absmax.view(N, num_blocks_per_row), functional.py:371-373)."""
+    from mps_bitsandbytes_amd.functional import _absmax_desc, _check_absmax_count
+    with pytest.raises(ValueError, match="cuda"):
+        _absmax_desc(torch.zeros(4), None, [])
+    with pytest.raises(ValueError, match="absmax has 7 elements, expected 8"):
+        _check_absmax_count(torch.zeros(7), 2, 256, 64, "matmul_4bit")
+    _check_absmax_count(torch.zeros(8), 2, 256, 64, "matmul_4bit")

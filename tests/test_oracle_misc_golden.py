@@ -1,0 +1,36 @@
+"""Round-2 small rows pinned on reference outputs (tests/golden/make_golden_misc.py -> g8_misc.npz / manifest_misc.json):
+the oracle's dequant_absmax (legacy form) bit-exactly, and BitsAndBytesConfig.from_dict's string parse."""
+import json
+import os
+
+import numpy as np
+import torch
+
+import oracle
+import mps_bitsandbytes_amd as bnb
+from tests.goldenio import HERE, from_bits
+
+MAN = json.load(open(os.path.join(HERE, "manifest_misc.json")))
+
+
+def load_case(npz, c):
+    k = f"da{c['id']}_"
+    q = torch.from_numpy(np.ascontiguousarray(npz[k + "q"])) if c["code"] != "f32" else from_bits(npz[k + "q"])
+    scales, out = from_bits(npz[k + "scales"]), from_bits(npz[k + "out"])
+    if c.get("one_d"):
+        return q.view(-1), scales.view(-1), out.view(-1)
+    return q.view(c["rows"], c["num_blocks"]), scales.view(c["rows"], c["dq_blocks"]), out.view(c["rows"], c["num_blocks"])
+
+
+def test_oracle_dequant_absmax_legacy_bit_exact():
+    npz = np.load(os.path.join(HERE, "g8_misc.npz"))
+    for c in MAN["dequant_absmax"]:
+        q, scales, want = load_case(npz, c)
+        got = oracle.dequant_absmax(q, scales, c["blocksize"])
+        assert got.shape == want.shape and torch.equal(got.view(torch.int32), want.view(torch.int32)), c
+
+
+def test_config_from_dict_string_dtype_matches_reference():
+    for rec in MAN["config_from_dict"]:
+        cfg = bnb.BitsAndBytesConfig.from_dict({"load_in_4bit": True, "bnb_4bit_compute_dtype": rec["in"]})
+        assert str(cfg.bnb_4bit_compute_dtype) == rec["out"], rec

@@ -40,6 +40,16 @@ def _worker(rank, world, port, M, return_dict):
         return_dict[rank] = bool(torch.equal(full, ref)) and tuple(full.shape) == (M, N)
         local = sharded_linear(X[s:e], fwd, M, gather=False)
         return_dict[f"local{rank}"] = bool(torch.equal(local, ref[s:e]))
+        if M % world == 0 and (M // world) % 2 == 0:
+            # row-chunked overlap inside one step: two steps through the two alternating buffers
+            from mps_bitsandbytes_amd.sharding import ChunkedGather
+            cg = ChunkedGather(fwd, e - s, N, torch.float16, "cpu", world, chunks=2)
+            ok = True
+            for _ in range(3):
+                view = cg.step(X[s:e])
+                cg.finish()
+                ok = ok and bool(torch.equal(view.reshape(M, N), ref))
+            return_dict[f"chunked{rank}"] = ok
     finally:
         dist.destroy_process_group()
 
@@ -60,3 +70,5 @@ def test_row_sharded_linear_allgather(world, M):
         assert p.exitcode == 0
     for r in range(world):
         assert ret[r] is True and ret[f"local{r}"] is True
+        if M % world == 0 and (M // world) % 2 == 0:
+            assert ret[f"chunked{r}"] is True

@@ -29,9 +29,26 @@ def stats(name, cmd, out):
                                                     r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"], r["StdDev"]))
 
 
-stats("trace", "python3 bench.py --no-cpu-baseline", "r01_bench_kernel_stats.csv")
-stats("nf4dq_ffn", "python3 bench.py --workload nf4dq_ffn --no-cpu-baseline --steps 50", "r01_nf4dq_ffn_kernel_stats.csv")
-stats("int8_4096", "python3 bench.py --workload int8_4096 --no-cpu-baseline --steps 50", "r01_int8_kernel_stats.csv")
+rnd = tag[:3]   # "r02x" -> files named r02_*
+stats("trace", "python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-empirical", f"{rnd}_bench_kernel_stats.csv")
+stats("nf4dq_ffn", "python3 bench.py --workload nf4dq_ffn --no-cpu-baseline --steps 50", f"{rnd}_nf4dq_ffn_kernel_stats.csv")
+stats("int8_4096", "python3 bench.py --workload int8_4096 --no-cpu-baseline --steps 50", f"{rnd}_int8_kernel_stats.csv")
+stats("nf4_m1", "python3 bench.py --workload nf4_m1 --no-cpu-baseline --steps 20", f"{rnd}_gemv_kernel_stats.csv")
+for fn in ("bench_driver", "bench"):
+    p = os.path.join(src, f"{tag}_{fn}.json")
+    if os.path.exists(p):
+        lines = [l for l in open(p) if l.startswith("{")]
+        if lines:
+            open(os.path.join(dst, f"{rnd}_{fn}_line.json"), "w").write(lines[-1])
+
+
+def kernel_counter_mean(dirname, kernel_substr, counter):
+    files = sorted(glob.glob(os.path.join(src, dirname, "*", "*counter_collection.csv")), key=os.path.getmtime)[-1:]
+    if not files:
+        return None
+    v = [float(r["Counter_Value"]) for r in csv.DictReader(open(files[0]))
+         if kernel_substr in r["Kernel_Name"] and r["Counter_Name"] == counter]
+    return (sum(v) / len(v), len(v)) if v else None
 
 res, dur = {}, []
 for name in ("fetch", "write", "tcc", "sq", "lds"):
@@ -69,5 +86,14 @@ if "FETCH_SIZE" in res:
             if k in res:
                 out[k + "_per_wave_cycle"] = res[k]["mean"] / wc
     out["counters"] = res
+    # HBM traffic of the GEMV (M = 1, 64 rotating layers) and of the int8 GEMM, same counters and correction
+    for wl, sub, key, alg in (("nf4_m1", "k_gemv4", "k_gemv4_bytes_per_launch", 9453568),
+                              ("int8_4096", "k_gemm_i8", "k_gemm_i8_bytes_per_launch", 2 * 4096 * 4096 + 4096 * 4096 * 2 + 2 * 4096 * 4)):
+        f = kernel_counter_mean(f"{tag}_{wl}_fetch", sub, "FETCH_SIZE")
+        w = kernel_counter_mean(f"{tag}_{wl}_write", sub, "WRITE_SIZE")
+        if f and w:
+            out[key] = int((2 * f[0] + w[0]) * 1024)
+            out[key.replace("_bytes_per_launch", "_detail")] = {"FETCH_SIZE_KB_raw": f[0], "WRITE_SIZE_KB": w[0], "dispatches": f[1],
+                                                                "algorithmic_bytes_per_launch": alg}
     json.dump(out, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
     print(json.dumps({k: v for k, v in out.items() if k != "counters"}, indent=1))
