@@ -19,10 +19,16 @@
 
 namespace mbnb {
 
-// four-wave cut of the 256 x 256 kernel (gemm256q.h), compiled in gemm256q.hip
+// shipping 256 x 256 kernel for blocksize 64 (gemm256s.h), compiled in gemm256s.hip
 template <typename T, bool NESTED>
-int launch_gemm256q(const T *x, const typename Q4ProducerRT<T, NESTED>::Params &wp, const T *bias, void *out, int out_dtype,
+int launch_gemm256s(const T *x, const typename Q4ProducerRT<T, NESTED>::Params &wp, const T *bias, void *out, int out_dtype,
                     int64_t M, int64_t N, int64_t K, hipStream_t st);
+
+// mid-sized batches (gemm_mid.h), compiled in gemm_mid.hip
+template <typename T, typename OutT, bool NESTED, int ABL = 0>
+int launch_gemm_mid(const T *x, const typename Q4ProducerRT<T, NESTED>::Params &wp, const T *bias, OutT *out, int64_t M,
+                    int64_t N, int64_t K, float *ws, int64_t ws_bytes, int force_slices, hipStream_t st);
+bool gemm_mid_shape(int64_t M, int64_t N, int64_t K);
 
 // =====================================================================================
 // generic kernel: wave per (n, m-chunk of MT rows); lanes stride over k in steps of 8
@@ -503,6 +509,16 @@ static int launch_matmul4(const void *A, int64_t M, int64_t K, const uint8_t *pa
             set_kernel_name("skinny_mfma16");
             return check_launch("matmul_4bit(skinny)");
         }
+        if (fast_layout && blocksize == 64 && (K_weight % 256 == 0) && gemm_mid_shape(M, N, K)) {
+            // mid-sized batches: 128 x 64 tiles on the LDS-DMA pipeline, K split over the caller's workspace when given
+            bool ok = true;
+            if constexpr (NESTED) ok = am.bs2 >= 4 && (am.bs2 & (am.bs2 - 1)) == 0 && (reinterpret_cast<uintptr_t>(am.i8) & 3) == 0;
+            if (ok) {
+                using P = Q4ProducerRT<T, NESTED>;
+                typename P::Params wp{packed, am, N, K_weight, K_weight / blocksize, 6, QT, NESTED ? ilog2(am.bs2) : 0, 8, 6};
+                return launch_gemm_mid<T, OutT, NESTED>(x, wp, b, o, M, N, K, ws, ws_bytes, 0, st);
+            }
+        }
         if (fast_layout && (K % 64 == 0) && ((M + 255) / 256) * ((N + 255) / 256) >= 96) {
             // large problems: 256 x 256 tiles, one workgroup per CU
             using P = Q4ProducerRT<T, NESTED>;
@@ -519,18 +535,22 @@ static int launch_matmul4(const void *A, int64_t M, int64_t K, const uint8_t *pa
 #ifdef MBNB_ABLATION
                 static const bool no_blut = getenv("MBNB_NO_BLUT") != nullptr;
                 static const bool no_am4 = getenv("MBNB_NO_AM4") != nullptr;
-                static const bool use_q = getenv("MBNB_Q4W") != nullptr;   // four-wave variant (gemm256q.h)
 #else
-                constexpr bool no_blut = false, no_am4 = false, use_q = false;
+                constexpr bool no_blut = false, no_am4 = false;
 #endif
                 KernT kern = no_blut ? k_gemm256p<T, NESTED> : k_gemm256p<T, NESTED, 0, false, true>;
                 bool am4 = !no_am4 && blocksize == 64 && (K_weight % 256 == 0);
                 if constexpr (NESTED) am4 = am4 && am.bs2 >= 4 && (reinterpret_cast<uintptr_t>(am.i8) & 3) == 0;
                 if (am4) kern = no_blut ? k_gemm256p<T, NESTED, 0, true> : k_gemm256p<T, NESTED, 0, true, true>;
-                if (use_q && am4 && (int64_t)M * K * (int64_t)sizeof(T) < (1ll << 32) && N * K_weight / 2 < (1ll << 32) &&
-                    N * (K_weight / blocksize) < (1ll << 32)) {
-                    set_kernel_name("mfma256q");
-                    return launch_gemm256q<T, NESTED>(x, wp, b, static_cast<void *>(o), od, M, N, K, st);
+#ifdef MBNB_ABLATION
+                static const bool use_p = getenv("MBNB_256P") != nullptr;   // diagnostic builds: the round-1 kernel for every shape
+#else
+                constexpr bool use_p = false;
+#endif
+                if (am4 && !use_p) {
+                    // blocksize 64: k_gemm256s (absmax-by-4, byte table, packed weights two k-steps per fetch)
+                    set_kernel_name("mfma256");
+                    return launch_gemm256s<T, NESTED>(x, wp, b, static_cast<void *>(o), od, M, N, K, st);
                 }
 #ifdef MBNB_ABLATION
                 // diagnostic builds: the measured schedule alternatives

@@ -32,7 +32,7 @@
 // waits in k_gemm256p / k_gemm256w / k_gemm_i8_256 (two waves hide the drains), an L2 prefetch of the next k-steps' lines
 // by one wave per workgroup (+2 us), un-swizzled DMA sources (no change), per-wave staggered DMA issue (no change).
 #pragma once
-#include "gemm256.h"
+#include "../../mps_bitsandbytes_amd/csrc/gemm256.h"
 #include <utility>
 
 namespace mbnb {
