@@ -158,9 +158,13 @@ int mbnb_matmul_4bit_ws(const void *A, int64_t M, int64_t K, const uint8_t *pack
  * matmul_int8 — replaces `_C.matmul_int8` (mm:1789-1834, kernel mm:155-196) /
  * functional.matmul_int8 (functional.py:788-793):
  *   out[M,N] = cast( int32(A[M,K] · B[K,N]) * (A_scales[m]/127) * (B_scales[n]/127) )
- * on the int8 MFMA.  `workspace` must hold N*K bytes (B is re-laid out K-contiguous);
- * it may be reused as soon as the call's work has completed on `stream`.
+ * on the int8 MFMA.  B is read as the reference passes it, [K, N] row-major.  Large aligned problems (K % 128 == 0,
+ * N % 16 == 0, 16-byte aligned A and B, >= 96 output tiles of 256 x 256) need NO workspace: the kernel transposes while it
+ * reads its LDS image (ds_read_b64_tr_b8).  Otherwise `workspace` must hold mbnb_matmul_int8_workspace_bytes(M, N, K)
+ * (= N*K) bytes, where B is first re-laid out K-contiguous; it may be reused as soon as the call's work has completed on
+ * `stream`; workspace == NULL selects a slow generic kernel for those shapes.
  * ------------------------------------------------------------------------- */
+int64_t mbnb_matmul_int8_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int mbnb_matmul_int8(const int8_t *A, const int8_t *B, const float *A_scales,
                      const float *B_scales, int64_t M, int64_t N, int64_t K, int out_dtype,
                      void *out, void *workspace, void *stream);

@@ -53,6 +53,7 @@ _SIGNATURES = {
     "mbnb_matmul_4bit_workspace_bytes": (c_int64, [c_int64, c_int64, c_int64]),
     "mbnb_matmul_4bit_ws": (c_int, [c_void_p, c_int64, c_int64, c_void_p, POINTER(AbsmaxDesc), c_int64, c_int64,
                                     c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p]),
+    "mbnb_matmul_int8_workspace_bytes": (c_int64, [c_int64, c_int64, c_int64]),
     "mbnb_matmul_int8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int,
                                  c_void_p, c_void_p, c_void_p]),
     "mbnb_linear_int8": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p,

@@ -70,6 +70,7 @@ int linear_fp8_dispatch(const void *, int, int64_t, int64_t, const uint8_t *, co
 int64_t matmul4_splitk_slices(int64_t, int64_t, int64_t);
 int64_t gemm_mid_workspace_bytes(int64_t, int64_t, int64_t);
 int matmul_int8_dispatch(const int8_t *, const int8_t *, const float *, const float *, int64_t, int64_t, int64_t, int, void *, void *, hipStream_t);
+int64_t matmul_int8_workspace_bytes(int64_t, int64_t, int64_t);
 int linear_int8_dispatch(const void *, int, int64_t, int64_t, const int8_t *, const float *, int64_t, const void *, void *, void *, int64_t, hipStream_t);
 int embedding_4bit_dispatch(const int64_t *, int64_t, const uint8_t *, const float *, int64_t, int64_t, int, int, int, int64_t, int, void *, hipStream_t);
 int embedding_8bit_dispatch(const int64_t *, int64_t, const int8_t *, const float *, int64_t, int64_t, int, int64_t, int, void *, hipStream_t);
@@ -231,6 +232,11 @@ int64_t mbnb_matmul_4bit_workspace_bytes(int64_t M, int64_t N, int64_t K) {
     const int64_t a = s > 1 ? s * ((M + 127) / 128) * ((N + 127) / 128) * 65536 : 0;   // slices x tiles x 128 x 128 f32
     const int64_t b = gemm_mid_workspace_bytes(M, N, K);   // slices x M x N f32 (mid-sized batches, blocksize 64)
     return a > b ? a : b;
+}
+
+int64_t mbnb_matmul_int8_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    return matmul_int8_workspace_bytes(M, N, K);
 }
 
 int mbnb_matmul_int8(const int8_t *A, const int8_t *B, const float *A_scales, const float *B_scales, int64_t M,

@@ -172,127 +172,12 @@ struct OutlierEpilogue {
     const void *bias;     // [N] or nullptr
 };
 
+// Epilogue of the 256 x 256 int8 kernels (wave tile 128 n x 64 m, acc[i][j][4g+e] = out[m0 + 64 wm + 32 j + fr][n0 + 128 wn +
+// 32 i + 8 g + 4 fh + e]): scales, optional outlier term and bias (OutlierEpilogue), rounding chain of the reference.
 template <typename OutT>
-__global__ __launch_bounds__(512, 2) void k_gemm_i8_256(const int8_t *__restrict__ A, const int8_t *__restrict__ Bt,
-                                                        const float *__restrict__ sA, const float *__restrict__ sB,
-                                                        OutT *__restrict__ out, int64_t M, int64_t N, int64_t K,
-                                                        OutlierEpilogue ep) {
-    extern __shared__ __attribute__((aligned(1024))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wave >> 2, wm = wave & 3;
-    const int64_t tiles_m = (M + 255) >> 8, tiles_n = (N + 255) >> 8;
-    const int64_t nwg = tiles_m * tiles_n;
-    int64_t bid = blockIdx.x;
-    {
-        const int64_t q = nwg / 8, r = nwg % 8, xcd = bid % 8;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
-    }
-    int64_t tm, tn;
-    if ((tiles_m % 4 == 0) && (tiles_n % 8 == 0)) {
-        const int64_t patch = bid >> 5, within = bid & 31;
-        const int64_t patches_m = tiles_m >> 2;
-        tm = (patch % patches_m) * 4 + (within & 3);
-        tn = (patch / patches_m) * 8 + (within >> 2);
-    } else {
-        tm = bid % tiles_m;
-        tn = bid / tiles_m;
-    }
-    const int64_t m0 = tm << 8, n0 = tn << 8;
-
-    // DMA pieces: wave w moves rows 32w .. 32w+31 of both images (4 pieces of 8 rows each), swizzle on the source
-    const int8_t *a_src[4], *b_src[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int row = 8 * (wave * 4 + i) + (lane >> 3);
-        const int c = (lane & 7) ^ ((row >> 1) & 7);
-        int64_t m = m0 + row, n = n0 + row;
-        m = m < M ? m : M - 1;
-        n = n < N ? n : N - 1;
-        a_src[i] = A + m * K + 16 * c;
-        b_src[i] = Bt + n * K + 16 * c;
-    }
-    auto issue_piece = [&](int stage, int64_t k0, int p) {  // p 0..3: A pieces, 4..7: B pieces
-        const int i = p & 3;
-        auto g = (const __attribute__((address_space(1))) void *)((p < 4 ? a_src[i] : b_src[i]) + k0);
-        auto l = (__attribute__((address_space(3))) void *)(smem + (p < 4 ? P_A : P_B) + stage * P_IMG + (wave * 4 + i) * 1024);
-        __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
-    };
-    const int fr = lane & 31, fh = lane >> 5;
-    int fw[4], fx[4];
-#pragma unroll
-    for (int s = 0; s < 4; s++) {
-        const int f = fr * ROW_BYTES + (((2 * s + fh) ^ ((fr >> 1) & 7)) << 4);
-        fw[s] = P_B + wn * 128 * ROW_BYTES + f;
-        fx[s] = P_A + wm * 64 * ROW_BYTES + f;
-    }
-    auto read_frags = [&](int stage, int s, i32x4 (&wf)[4], i32x4 (&xf)[2]) {
-#pragma unroll
-        for (int i = 0; i < 4; i++) wf[i] = *reinterpret_cast<const i32x4 *>(smem + fw[s] + stage * P_IMG + i * 32 * ROW_BYTES);
-#pragma unroll
-        for (int j = 0; j < 2; j++) xf[j] = *reinterpret_cast<const i32x4 *>(smem + fx[s] + stage * P_IMG + j * 32 * ROW_BYTES);
-    };
-    i32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int e = 0; e < 16; e++) acc[i][j][e] = 0;
-
-    const int64_t nk = K >> 7;
-    const int64_t k_last = (nk - 1) << 7;
-    auto kclamp = [&](int64_t t) { return t < nk ? t << 7 : k_last; };
-
-#pragma unroll
-    for (int p = 0; p < 8; p++) issue_piece(0, 0, p);
-#pragma unroll
-    for (int p = 0; p < 8; p++) issue_piece(1, kclamp(1), p);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // tile 0 landed (tile 1 still in flight)
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    i32x4 wfA[4], xfA[2], wfB[4], xfB[2];
-    read_frags(0, 0, wfA, xfA);
-
-    auto group = [&](const i32x4 (&wf)[4], const i32x4 (&xf)[2], auto &&filler) {
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-                acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[i], xf[j], acc[i][j], 0, 0, 0);
-                filler(i * 2 + j);
-            }
-    };
-    auto kstep = [&](auto cc, int64_t j) {
-        constexpr int C = decltype(cc)::value, Nn = C ^ 1;
-        read_frags(C, 1, wfB, xfB);
-        __builtin_amdgcn_sched_barrier(0);
-        group(wfA, xfA, [](int) {});
-        __builtin_amdgcn_sched_barrier(0);
-        read_frags(C, 2, wfA, xfA);
-        __builtin_amdgcn_sched_barrier(0);
-        group(wfB, xfB, [](int) {});
-        __builtin_amdgcn_sched_barrier(0);
-        read_frags(C, 3, wfB, xfB);
-        __builtin_amdgcn_sched_barrier(0);
-        group(wfA, xfA, [](int) {});
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // tile j+1 landed (issued one k-step ago)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                        // stage Nn complete, stage C free
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        read_frags(Nn, 0, wfA, xfA);
-        __builtin_amdgcn_sched_barrier(0);
-        group(wfB, xfB, [&](int r) { issue_piece(C, kclamp(j + 2), r); });  // one DMA piece behind each MFMA
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    for (int64_t j = 0; j < nk; j += 2) {
-        kstep(std::integral_constant<int, 0>{}, j);
-        if (j + 1 < nk) kstep(std::integral_constant<int, 1>{}, j + 1);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
+__device__ __forceinline__ void i8_256_epilogue(const i32x16 (&acc)[4][2], const float *__restrict__ sA, const float *__restrict__ sB,
+                                                OutT *__restrict__ out, int64_t M, int64_t N, int64_t m0, int64_t n0, int wn,
+                                                int wm, int fr, int fh, const OutlierEpilogue &ep) {
     const bool with_outliers = ep.x != nullptr && ep.n_out > 0;   // the dispatcher sends n_out <= 16 only
     const OutT *bias = static_cast<const OutT *>(ep.bias);
     // outlier operands of this wave, fetched once: 4 weight fragments (rows n, 8 consecutive outliers per lane half: one
@@ -364,6 +249,157 @@ __global__ __launch_bounds__(512, 2) void k_gemm_i8_256(const int8_t *__restrict
             }
         }
     }
+}
+
+template <typename OutT, bool BNN = false>
+__global__ __launch_bounds__(512, 2) void k_gemm_i8_256(const int8_t *__restrict__ A, const int8_t *__restrict__ Bt,
+                                                        const float *__restrict__ sA, const float *__restrict__ sB,
+                                                        OutT *__restrict__ out, int64_t M, int64_t N, int64_t K,
+                                                        OutlierEpilogue ep) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave >> 2, wm = wave & 3;
+    const int64_t tiles_m = (M + 255) >> 8, tiles_n = (N + 255) >> 8;
+    const int64_t nwg = tiles_m * tiles_n;
+    int64_t bid = blockIdx.x;
+    {
+        const int64_t q = nwg / 8, r = nwg % 8, xcd = bid % 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+    }
+    int64_t tm, tn;
+    if ((tiles_m % 4 == 0) && (tiles_n % 8 == 0)) {
+        const int64_t patch = bid >> 5, within = bid & 31;
+        const int64_t patches_m = tiles_m >> 2;
+        tm = (patch % patches_m) * 4 + (within & 3);
+        tn = (patch / patches_m) * 8 + (within >> 2);
+    } else {
+        tm = bid % tiles_m;
+        tn = bid / tiles_m;
+    }
+    const int64_t m0 = tm << 8, n0 = tn << 8;
+
+    // DMA pieces: wave w moves rows 32w .. 32w+31 of the activation image (4 pieces of 8 rows x 128 B), swizzle on the
+    // source.  Weight image, BNN = false: B^T [N, K], the same shape.  BNN = true: B as it lies, [K, N] row-major
+    // (functional.py:788-793): the image is [128 k][256 n], wave w moves k-rows 16w .. 16w+15 (4 pieces of 4 rows x 256 B,
+    // whole lines), 16-byte chunk c of row k stored at position c ^ ((k & 7) << 1); the MFMA operand (16 consecutive k
+    // of one n per lane) comes out of it with two ds_read_b64_tr_b8 -- no transpose kernel, no workspace.
+    const int8_t *a_src[4], *b_src[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int row = 8 * (wave * 4 + i) + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        int64_t m = m0 + row, n = n0 + row;
+        m = m < M ? m : M - 1;
+        n = n < N ? n : N - 1;
+        a_src[i] = A + m * K + 16 * c;
+        if constexpr (!BNN) {
+            b_src[i] = Bt + n * K + 16 * c;
+        } else {
+            const int kr = 4 * (wave * 4 + i) + (lane >> 4);
+            int c16 = (lane & 15) ^ ((kr & 7) << 1);
+            if (n0 + 16 * c16 + 16 > N) c16 = 0;      // columns past N: re-read chunk 0 (never stored)
+            b_src[i] = Bt + (int64_t)kr * N + n0 + 16 * c16;
+        }
+    }
+    auto issue_piece = [&](int stage, int64_t k0, int p) {  // p 0..3: A pieces, 4..7: B pieces
+        const int i = p & 3;
+        const int8_t *src = p < 4 ? a_src[i] + k0 : (BNN ? b_src[i] + k0 * N : b_src[i] + k0);
+        auto g = (const __attribute__((address_space(1))) void *)src;
+        auto l = (__attribute__((address_space(3))) void *)(smem + (p < 4 ? P_A : P_B) + stage * P_IMG + (wave * 4 + i) * 1024);
+        __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
+    };
+    const int fr = lane & 31, fh = lane >> 5;
+    int fw[4], fx[4], fwt[4][2];
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        const int f = fr * ROW_BYTES + (((2 * s + fh) ^ ((fr >> 1) & 7)) << 4);
+        fw[s] = P_B + wn * 128 * ROW_BYTES + f;
+        fx[s] = P_A + wm * 64 * ROW_BYTES + f;
+        // transposing reads: lane l = 16 g + 2 q + p; read r of MFMA group s covers k-rows 32 s + 16 fh + 8 r + q
+        const int q = (lane & 15) >> 1, p = lane & 1, gsel = (lane >> 4) & 1;
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+            fwt[s][r] = P_B + (32 * s + 16 * fh + 8 * r + q) * 256 + (((wn * 8 + gsel) ^ (q << 1)) << 4) + 8 * p;
+    }
+    auto read_frags = [&](int stage, int s, i32x4 (&wf)[4], i32x4 (&xf)[2]) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if constexpr (!BNN) {
+                wf[i] = *reinterpret_cast<const i32x4 *>(smem + fw[s] + stage * P_IMG + i * 32 * ROW_BYTES);
+            } else {
+                // tile i: chunk 8 wn + 2 i + gsel (disjoint bit fields) -> the i = 0 address ^ (i << 5)
+                typedef int v2i __attribute__((ext_vector_type(2)));
+                const v2i lo = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) v2i *)(smem + stage * P_IMG + (fwt[s][0] ^ (i << 5))));
+                const v2i hi = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) v2i *)(smem + stage * P_IMG + (fwt[s][1] ^ (i << 5))));
+                wf[i] = i32x4{lo[0], lo[1], hi[0], hi[1]};
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; j++) xf[j] = *reinterpret_cast<const i32x4 *>(smem + fx[s] + stage * P_IMG + j * 32 * ROW_BYTES);
+    };
+    i32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0;
+
+    const int64_t nk = K >> 7;
+    const int64_t k_last = (nk - 1) << 7;
+    auto kclamp = [&](int64_t t) { return t < nk ? t << 7 : k_last; };
+
+#pragma unroll
+    for (int p = 0; p < 8; p++) issue_piece(0, 0, p);
+#pragma unroll
+    for (int p = 0; p < 8; p++) issue_piece(1, kclamp(1), p);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // tile 0 landed (tile 1 still in flight)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    i32x4 wfA[4], xfA[2], wfB[4], xfB[2];
+    read_frags(0, 0, wfA, xfA);
+
+    auto group = [&](const i32x4 (&wf)[4], const i32x4 (&xf)[2], auto &&filler) {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[i], xf[j], acc[i][j], 0, 0, 0);
+                filler(i * 2 + j);
+            }
+    };
+    auto kstep = [&](auto cc, int64_t j) {
+        constexpr int C = decltype(cc)::value, Nn = C ^ 1;
+        read_frags(C, 1, wfB, xfB);
+        __builtin_amdgcn_sched_barrier(0);
+        group(wfA, xfA, [](int) {});
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(C, 2, wfA, xfA);
+        __builtin_amdgcn_sched_barrier(0);
+        group(wfB, xfB, [](int) {});
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(C, 3, wfB, xfB);
+        __builtin_amdgcn_sched_barrier(0);
+        group(wfA, xfA, [](int) {});
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // tile j+1 landed (issued one k-step ago)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                        // stage Nn complete, stage C free
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(Nn, 0, wfA, xfA);
+        __builtin_amdgcn_sched_barrier(0);
+        group(wfB, xfB, [&](int r) { issue_piece(C, kclamp(j + 2), r); });  // one DMA piece behind each MFMA
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int64_t j = 0; j < nk; j += 2) {
+        kstep(std::integral_constant<int, 0>{}, j);
+        if (j + 1 < nk) kstep(std::integral_constant<int, 1>{}, j + 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    i8_256_epilogue<OutT>(acc, sA, sB, out, M, N, m0, n0, wn, wm, fr, fh, ep);
 }
 
 // odd K (not a multiple of 16) or unaligned pointers: one wave per output element row
@@ -450,8 +486,38 @@ int matmul_int8_nt_dispatch(const int8_t *A, const int8_t *Bt, const float *sA, 
     return check_launch("matmul_int8(mfma)");
 }
 
+// matmul_int8 reads B as the reference passes it, [K, N] row-major.  Large aligned problems go straight to the 256 x 256
+// kernel's transposing-read form (no workspace); everything else is first re-laid out K-contiguous into the caller's
+// workspace (N * K bytes) or, without one, served by the generic kernel.
+bool matmul_int8_direct(const int8_t *A, const int8_t *B, int64_t M, int64_t N, int64_t K) {
+    return (K % 128 == 0) && (N % 16 == 0) && ((M + 255) / 256) * ((N + 255) / 256) >= 96 &&
+           ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0;
+}
+int64_t matmul_int8_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+    return matmul_int8_direct(nullptr, nullptr, M, N, K) ? 0 : N * K;
+}
+
 int matmul_int8_dispatch(const int8_t *A, const int8_t *B, const float *sA, const float *sB, int64_t M, int64_t N,
                          int64_t K, int out_dtype, void *out, void *workspace, hipStream_t st) {
+    if (matmul_int8_direct(A, B, M, N, K)) {
+        const int64_t tiles256 = ((M + 255) / 256) * ((N + 255) / 256);
+        constexpr int lds256 = 4 * P_IMG;
+        OutlierEpilogue epv{nullptr, 0, nullptr, 0, nullptr, nullptr};
+#define MBNB_I8_NN(OT)                                                                                               \
+    do {                                                                                                             \
+        auto kern = k_gemm_i8_256<OT, true>;                                                                         \
+        if (int rc = ensure_dyn_lds(reinterpret_cast<const void *>(kern), lds256, "matmul_int8(mfma256)")) return rc;  \
+        hipLaunchKernelGGL(kern, dim3((unsigned)tiles256), dim3(512), lds256, st, A, B, sA, sB, static_cast<OT *>(out), M, N, K, epv); \
+    } while (0)
+        switch (out_dtype) {
+            case MBNB_F16: MBNB_I8_NN(f16_t); break;
+            case MBNB_BF16: MBNB_I8_NN(bf16_t); break;
+            default: MBNB_I8_NN(float); break;
+        }
+#undef MBNB_I8_NN
+        set_kernel_name("i8_mfma256");
+        return check_launch("matmul_int8(mfma256)");
+    }
     const bool fast = (K % 16 == 0) && workspace != nullptr &&
                       ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(workspace)) & 15) == 0;
     if (!fast) {

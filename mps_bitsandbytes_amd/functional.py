@@ -568,7 +568,9 @@ def matmul_int8(A: Tensor, B: Tensor, A_scales: Tensor, B_scales: Tensor,
         raise ValueError(f"matmul_int8: need {M} A_scales and {N} B_scales, got {sa.numel()} and {sb.numel()}")
     out_dtype = dtype if dtype in _native.DTYPE_CODE else torch.float32
     out = torch.empty(M, N, dtype=out_dtype, device=A.device)
-    workspace = torch.empty(N * K, dtype=torch.int8, device=A.device)
+    # large aligned problems are read in place ([K, N] through a transposing LDS read); the rest need an N*K-byte scratch
+    ws_bytes = int(_native.lib().mbnb_matmul_int8_workspace_bytes(M, N, K))
+    workspace = torch.empty(ws_bytes, dtype=torch.int8, device=A.device) if ws_bytes > 0 else None
     with torch.cuda.device(A.device):
         check(_native.lib().mbnb_matmul_int8(
             ptr(A), ptr(B), ptr(sa), ptr(sb), M, N, K, _native.DTYPE_CODE[out_dtype], ptr(out), ptr(workspace),
