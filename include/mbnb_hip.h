@@ -83,6 +83,15 @@ int mbnb_quantize_4bit(const void *A, int dtype, int64_t rows, int64_t cols, int
                        int blocksize, int quant_type, const float *absmax_in, uint8_t *packed,
                        float *absmax_out, void *stream);
 
+/* quantize_4bit with compress_statistics=True in one launch — functional.py:163-303 including :288-292
+ * (`absmax, state2 = quantize_blockwise(absmax, blocksize=256)`): packed nibbles as mbnb_quantize_4bit, and instead of
+ * the f32 absmax its double-quantised form: int8 codes [rows * cols_padded / blocksize] and one f32 absmax2 per 256 codes
+ * [ceil(nblocks / 256)], bit-identical to mbnb_quantize_4bit followed by mbnb_quantize_blockwise(absmax, 256).
+ * blocksize: power of two in [8, 512] (otherwise MBNB_ERR_UNSUPPORTED: use the two calls). */
+int mbnb_quantize_4bit_dq(const void *A, int dtype, int64_t rows, int64_t cols, int64_t cols_padded,
+                          int blocksize, int quant_type, uint8_t *packed, int8_t *absmax_codes,
+                          float *absmax2, void *stream);
+
 /* dequantize_4bit — replaces functional.dequantize_4bit (functional.py:306-416; dead native
  * binding `_C.dequantize_nf4/_fp4`, mm:1927-1954 / :2739).  out [rows, cols] of out_dtype. */
 int mbnb_dequantize_4bit(const uint8_t *packed, const mbnb_absmax *absmax, int64_t rows,
@@ -211,12 +220,20 @@ int mbnb_embedding_8bit(const int64_t *indices, int64_t n_indices, const int8_t 
  *   main   = int32(q . W_i8[N,K]^T) * (s[m]/127) * (W_scales[n]/127)  rounded to dtype  (:133-138, on the int8 MFMA;
  *            the reference multiplies dtype-rounded dequantised operands instead: <= 4e-4 (f16) / 1.3e-3 (bf16) rel.)
  *   out    = RNE(RNE(main + RNE(X[:, outlier_idx] . outlier_w^T)) + bias)               (:141-143, :110-111)
- * n_outliers may be 0 (pure INT8 path, :100-105).  `workspace` must hold mbnb_outlier_linear_workspace_bytes(M, K).
+ * n_outliers may be 0 (pure INT8 path, :100-105).  `workspace` holds the int8 activations, their row scales and the
+ * compact outlier activations [M, 16 * ceil(n_outliers / 16)]: mbnb_outlier_linear_workspace_bytes_n(M, K, n_outliers)
+ * bytes let the 256 x 256 kernel fold ANY number of outlier columns (and the bias) into its epilogue, one 16-bit MFMA
+ * per tile and 16 columns; the two-argument query (and mbnb_outlier_linear, which assumes it) has room for 16 columns --
+ * with more than that the outlier term runs as a separate pass over the output (same results).
  * ------------------------------------------------------------------------- */
 int64_t mbnb_outlier_linear_workspace_bytes(int64_t M, int64_t K);
+int64_t mbnb_outlier_linear_workspace_bytes_n(int64_t M, int64_t K, int64_t n_outliers);
 int mbnb_outlier_linear(const void *X, int dtype, int64_t M, int64_t K, const int8_t *W, const float *W_scales,
                         int64_t N, const int64_t *outlier_idx, int64_t n_outliers, const void *outlier_w,
                         const void *bias, void *out, void *workspace, void *stream);
+int mbnb_outlier_linear_ws(const void *X, int dtype, int64_t M, int64_t K, const int8_t *W, const float *W_scales,
+                           int64_t N, const int64_t *outlier_idx, int64_t n_outliers, const void *outlier_w,
+                           const void *bias, void *out, void *workspace, int64_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------
  * FP8 E4M3 in the reference's own format — replaces `_C.quantize_fp8_e4m3` / `_C.dequantize_fp8_e4m3` /

@@ -39,6 +39,8 @@ _SIGNATURES = {
     "mbnb_last_kernel": (c_char_p, []),
     "mbnb_quantize_4bit": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_int, c_int, c_void_p,
                                    c_void_p, c_void_p, c_void_p]),
+    "mbnb_quantize_4bit_dq": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                      c_void_p]),
     "mbnb_dequantize_4bit": (c_int, [c_void_p, POINTER(AbsmaxDesc), c_int64, c_int64, c_int64, c_int, c_int,
                                      c_int, c_void_p, c_void_p]),
     "mbnb_quantize_blockwise": (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -69,6 +71,9 @@ _SIGNATURES = {
     "mbnb_embedding_8bit": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int64, c_int,
                                     c_void_p, c_void_p]),
     "mbnb_outlier_linear_workspace_bytes": (c_int64, [c_int64, c_int64]),
+    "mbnb_outlier_linear_workspace_bytes_n": (c_int64, [c_int64, c_int64, c_int64]),
+    "mbnb_outlier_linear_ws": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
+                                       c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "mbnb_outlier_linear": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
 }

@@ -56,6 +56,7 @@ int check_launch(const char *what) {
 
 // launchers (quant_kernels.hip, matmul4_kernels.hip, int8_kernels.hip)
 int quantize_4bit_dispatch(const void *, int, int64_t, int64_t, int64_t, int, int, const float *, uint8_t *, float *, hipStream_t);
+int quantize_4bit_dq_dispatch(const void *, int, int64_t, int64_t, int64_t, int, int, uint8_t *, int8_t *, float *, hipStream_t);
 int dequantize_4bit_dispatch(const uint8_t *, const AbsmaxView &, int64_t, int64_t, int64_t, int, int, int, void *, hipStream_t);
 int quantize_blockwise_dispatch(const void *, int, int64_t, int, const float *, int8_t *, float *, hipStream_t);
 int dequantize_blockwise_dispatch(const int8_t *, int64_t, const float *, int, int, void *, hipStream_t);
@@ -74,7 +75,8 @@ int64_t matmul_int8_workspace_bytes(int64_t, int64_t, int64_t);
 int linear_int8_dispatch(const void *, int, int64_t, int64_t, const int8_t *, const float *, int64_t, const void *, void *, void *, int64_t, hipStream_t);
 int embedding_4bit_dispatch(const int64_t *, int64_t, const uint8_t *, const float *, int64_t, int64_t, int, int, int, int64_t, int, void *, hipStream_t);
 int embedding_8bit_dispatch(const int64_t *, int64_t, const int8_t *, const float *, int64_t, int64_t, int, int64_t, int, void *, hipStream_t);
-int outlier_linear_dispatch(const void *, int, int64_t, int64_t, const int8_t *, const float *, int64_t, const int64_t *, int64_t, const void *, const void *, void *, void *, hipStream_t);
+int outlier_linear_dispatch(const void *, int, int64_t, int64_t, const int8_t *, const float *, int64_t, const int64_t *, int64_t, const void *, const void *, void *, void *, int64_t, hipStream_t);
+int64_t outlier_linear_workspace_bytes(int64_t, int64_t, int64_t);
 
 static bool dtype_ok(int d) { return d == MBNB_F16 || d == MBNB_BF16 || d == MBNB_F32; }
 static bool qt_ok(int q) { return q == MBNB_NF4 || q == MBNB_FP4; }
@@ -125,6 +127,23 @@ int mbnb_quantize_4bit(const void *A, int dtype, int64_t rows, int64_t cols, int
     if (reinterpret_cast<uintptr_t>(packed) & 3) return fail(MBNB_ERR_ARG, "quantize_4bit: packed must be 4-byte aligned");
     return quantize_4bit_dispatch(A, dtype, rows, cols, cols_padded, blocksize, quant_type, absmax_in, packed,
                                   absmax_out, static_cast<hipStream_t>(stream));
+}
+
+int mbnb_quantize_4bit_dq(const void *A, int dtype, int64_t rows, int64_t cols, int64_t cols_padded, int blocksize,
+                          int quant_type, uint8_t *packed, int8_t *absmax_codes, float *absmax2, void *stream) {
+    if (!dtype_ok(dtype) || !qt_ok(quant_type)) return fail(MBNB_ERR_ARG, "quantize_4bit_dq: bad dtype/quant_type");
+    if (rows < 0 || cols < 0) return fail(MBNB_ERR_ARG, "quantize_4bit_dq: negative size");
+    if (!pow2(blocksize) || blocksize < 8 || blocksize > 512)
+        return fail(MBNB_ERR_UNSUPPORTED, "quantize_4bit_dq: blocksize must be a power of 2 in [8, 512], got %d "
+                                          "(use mbnb_quantize_4bit + mbnb_quantize_blockwise)", blocksize);
+    if (cols_padded < cols || cols_padded % blocksize || cols_padded % 2)
+        return fail(MBNB_ERR_SHAPE, "quantize_4bit_dq: cols_padded=%lld inconsistent with cols=%lld blocksize=%d",
+                    (long long)cols_padded, (long long)cols, blocksize);
+    if (rows == 0 || cols_padded == 0) return MBNB_OK;
+    if (!A || !packed || !absmax_codes || !absmax2) return fail(MBNB_ERR_ARG, "quantize_4bit_dq: NULL pointer");
+    if (reinterpret_cast<uintptr_t>(packed) & 3) return fail(MBNB_ERR_ARG, "quantize_4bit_dq: packed must be 4-byte aligned");
+    return quantize_4bit_dq_dispatch(A, dtype, rows, cols, cols_padded, blocksize, quant_type, packed, absmax_codes, absmax2,
+                                     static_cast<hipStream_t>(stream));
 }
 
 int mbnb_dequantize_4bit(const uint8_t *packed, const mbnb_absmax *absmax, int64_t rows, int64_t cols,
@@ -292,21 +311,36 @@ int mbnb_embedding_8bit(const int64_t *indices, int64_t n_indices, const int8_t 
 
 int64_t mbnb_outlier_linear_workspace_bytes(int64_t M, int64_t K) {
     if (M < 0 || K < 0) return 0;
-    // int8 activations + their row scales + the compact [M, 16] outlier activations (16-bit)
-    return ((M * K + 255) & ~(int64_t)255) + ((4 * M + 255) & ~(int64_t)255) + ((32 * M + 255) & ~(int64_t)255);
+    return outlier_linear_workspace_bytes(M, K, 16);     // room for one chunk of 16 outlier columns in the fused epilogue
+}
+int64_t mbnb_outlier_linear_workspace_bytes_n(int64_t M, int64_t K, int64_t n_outliers) {
+    if (M < 0 || K < 0 || n_outliers < 0) return 0;
+    return outlier_linear_workspace_bytes(M, K, n_outliers > 16 ? n_outliers : 16);
 }
 
-int mbnb_outlier_linear(const void *X, int dtype, int64_t M, int64_t K, const int8_t *W, const float *W_scales, int64_t N,
-                        const int64_t *outlier_idx, int64_t n_outliers, const void *outlier_w, const void *bias, void *out,
-                        void *workspace, void *stream) {
+int mbnb_outlier_linear_ws(const void *X, int dtype, int64_t M, int64_t K, const int8_t *W, const float *W_scales, int64_t N,
+                           const int64_t *outlier_idx, int64_t n_outliers, const void *outlier_w, const void *bias, void *out,
+                           void *workspace, int64_t workspace_bytes, void *stream) {
     if (!dtype_ok(dtype)) return fail(MBNB_ERR_ARG, "outlier_linear: bad dtype");
     if (M < 0 || N < 0 || K <= 0 || n_outliers < 0) return fail(MBNB_ERR_ARG, "outlier_linear: bad size");
     if (M == 0 || N == 0) return MBNB_OK;
     if (!X || !W || !W_scales || !out || !workspace) return fail(MBNB_ERR_ARG, "outlier_linear: NULL pointer");
     if (n_outliers > 0 && (!outlier_idx || !outlier_w)) return fail(MBNB_ERR_ARG, "outlier_linear: outliers without index/weight buffers");
+    if (workspace_bytes < outlier_linear_workspace_bytes(M, K, 0))
+        return fail(MBNB_ERR_ARG, "outlier_linear: workspace of %lld bytes is too small (need %lld)", (long long)workspace_bytes,
+                    (long long)outlier_linear_workspace_bytes(M, K, n_outliers));
     return outlier_linear_dispatch(X, dtype, M, K, W, W_scales, N, outlier_idx, n_outliers, outlier_w, bias, out, workspace,
-                                   static_cast<hipStream_t>(stream));
+                                   workspace_bytes, static_cast<hipStream_t>(stream));
 }
+
+int mbnb_outlier_linear(const void *X, int dtype, int64_t M, int64_t K, const int8_t *W, const float *W_scales, int64_t N,
+                        const int64_t *outlier_idx, int64_t n_outliers, const void *outlier_w, const void *bias, void *out,
+                        void *workspace, void *stream) {
+    // workspace sized by mbnb_outlier_linear_workspace_bytes(M, K): the fused epilogue serves up to 16 outlier columns
+    return mbnb_outlier_linear_ws(X, dtype, M, K, W, W_scales, N, outlier_idx, n_outliers, outlier_w, bias, out, workspace,
+                                  M >= 0 && K >= 0 ? outlier_linear_workspace_bytes(M, K, 16) : 0, stream);
+}
+
 
 int mbnb_quantize_fp8_e4m3(const void *A, int dtype, int64_t rows, int64_t cols, uint8_t *out, float *scales, void *stream) {
     if (!dtype_ok(dtype)) return fail(MBNB_ERR_ARG, "quantize_fp8_e4m3: bad dtype");

@@ -164,8 +164,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_i8(const int8_t *__restrict__ A
 //   out = RNE(RNE(RNE(acc * sA/127 * sB/127) + RNE(X[:, oidx] . ow^T)) + bias)
 // x == nullptr: no outlier term; bias == nullptr: no bias; both null: the plain matmul_int8 epilogue.
 struct OutlierEpilogue {
-    const void *x;        // [M, 16] outlier activations (compact, zero padded) in the output dtype (16-bit)
-    int64_t ldx;          // = 16
+    const void *x;        // [M, ldx] outlier activations (compact, zero padded) in the output dtype (16-bit)
+    int64_t ldx;          // = 16 * ceil(n_out / 16)
     const int64_t *oidx;  // [n_out]
     int64_t n_out;
     const void *ow;       // [N, n_out] outlier weights in the output dtype
@@ -178,34 +178,23 @@ template <typename OutT>
 __device__ __forceinline__ void i8_256_epilogue(const i32x16 (&acc)[4][2], const float *__restrict__ sA, const float *__restrict__ sB,
                                                 OutT *__restrict__ out, int64_t M, int64_t N, int64_t m0, int64_t n0, int wn,
                                                 int wm, int fr, int fh, const OutlierEpilogue &ep) {
-    const bool with_outliers = ep.x != nullptr && ep.n_out > 0;   // the dispatcher sends n_out <= 16 only
+    const bool with_outliers = ep.x != nullptr && ep.n_out > 0;
     const OutT *bias = static_cast<const OutT *>(ep.bias);
-    // outlier operands of this wave, fetched once: 4 weight fragments (rows n, 8 consecutive outliers per lane half: one
-    // 16-byte load when n_out == 16) and 2 activation fragments (rows m, 8 gathered columns)
-    u32x4 wfr[4], xfr[2];
+    // Outlier term: sum over the outlier columns of x[m, idx_j] * ow[n, j], one 16-bit MFMA per 32 x 32 tile and CHUNK of 16
+    // outliers (any number of chunks: the f32 accumulator runs through them, one rounding at the end as the reference's
+    // single GEMM, nn/outlier_aware.py:141-143).  ep.x: compact [M, ldx] outlier activations, zero padded to ldx =
+    // 16 * chunks, written by the quantize kernel; the weights [N, n_out] are read 8 at a time (one 16-byte load when the
+    // row is 16-byte aligned, a guarded gather at the ragged end).  The activation fragments of chunk 0 are fetched once.
+    const int64_t nchunks = with_outliers ? (ep.n_out + 15) / 16 : 0;
+    u32x4 xfr0[2];
     if constexpr (sizeof(OutT) == 2) {
         if (with_outliers) {
             const OutT *xx = static_cast<const OutT *>(ep.x);
-            const OutT *ow = static_cast<const OutT *>(ep.ow);
-            const bool vec = ep.n_out == 16 && ((reinterpret_cast<uintptr_t>(ow) & 15) == 0);
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                int64_t nrow = n0 + wn * 128 + i * 32 + fr;
-                nrow = nrow < N ? nrow : N - 1;
-                if (vec) {
-                    wfr[i] = *reinterpret_cast<const u32x4 *>(ow + nrow * 16 + 8 * fh);
-                } else {
-                    __attribute__((aligned(16))) OutT t[8];
-#pragma unroll
-                    for (int e = 0; e < 8; e++) t[e] = (8 * fh + e < ep.n_out) ? ow[nrow * ep.n_out + 8 * fh + e] : from_f32<OutT>(0.0f);
-                    wfr[i] = *reinterpret_cast<const u32x4 *>(t);
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 2; j++) {   // ep.x: compact [M, 16] outlier activations written by the quantize kernel
+            for (int j = 0; j < 2; j++) {
                 int64_t mrow = m0 + wm * 64 + j * 32 + fr;
                 mrow = mrow < M ? mrow : M - 1;
-                xfr[j] = *reinterpret_cast<const u32x4 *>(xx + mrow * 16 + 8 * fh);
+                xfr0[j] = *reinterpret_cast<const u32x4 *>(xx + mrow * ep.ldx + 8 * fh);
             }
         }
     }
@@ -213,12 +202,39 @@ __device__ __forceinline__ void i8_256_epilogue(const i32x16 (&acc)[4][2], const
     for (int i = 0; i < 4; i++) {
         f32x16 o[2];
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
+        for (int j = 0; j < 2; j++)
 #pragma unroll
             for (int e = 0; e < 16; e++) o[j][e] = 0.0f;
-            if constexpr (sizeof(OutT) == 2) {
-                using Fr = typename Mfma<OutT>::frag;
-                if (with_outliers) o[j] = Mfma<OutT>::run(__builtin_bit_cast(Fr, wfr[i]), __builtin_bit_cast(Fr, xfr[j]), o[j]);
+        if constexpr (sizeof(OutT) == 2) {
+            using Fr = typename Mfma<OutT>::frag;
+            if (with_outliers) {
+                const OutT *xx = static_cast<const OutT *>(ep.x);
+                const OutT *ow = static_cast<const OutT *>(ep.ow);
+                const bool vec = (ep.n_out % 8 == 0) && ((reinterpret_cast<uintptr_t>(ow) & 15) == 0);
+                int64_t nrow = n0 + wn * 128 + i * 32 + fr;
+                nrow = nrow < N ? nrow : N - 1;
+                for (int64_t c = 0; c < nchunks; c++) {
+                    const int64_t j0 = 16 * c + 8 * fh;      // first of this lane's 8 outliers
+                    u32x4 wfr;
+                    if (vec && j0 + 8 <= ep.n_out) {
+                        wfr = *reinterpret_cast<const u32x4 *>(ow + nrow * ep.n_out + j0);
+                    } else {
+                        __attribute__((aligned(16))) OutT t[8];
+#pragma unroll
+                        for (int e = 0; e < 8; e++) t[e] = (j0 + e < ep.n_out) ? ow[nrow * ep.n_out + j0 + e] : from_f32<OutT>(0.0f);
+                        wfr = *reinterpret_cast<const u32x4 *>(t);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 2; j++) {
+                        u32x4 xfr = xfr0[j];
+                        if (c > 0) {
+                            int64_t mrow = m0 + wm * 64 + j * 32 + fr;
+                            mrow = mrow < M ? mrow : M - 1;
+                            xfr = *reinterpret_cast<const u32x4 *>(xx + mrow * ep.ldx + 16 * c + 8 * fh);
+                        }
+                        o[j] = Mfma<OutT>::run(__builtin_bit_cast(Fr, wfr), __builtin_bit_cast(Fr, xfr), o[j]);
+                    }
+                }
             }
         }
 #pragma unroll
@@ -449,7 +465,7 @@ int matmul_int8_nt_dispatch(const int8_t *A, const int8_t *Bt, const float *sA, 
         const int64_t tiles256 = ((M + 255) / 256) * ((N + 255) / 256);
         constexpr int lds256 = 4 * P_IMG;
         OutlierEpilogue epv{nullptr, 0, nullptr, 0, nullptr, nullptr};
-        if (ep != nullptr && out_dtype != MBNB_F32 && ep->n_out <= 16) {
+        if (ep != nullptr && out_dtype != MBNB_F32) {
             epv = *ep;
             if (ep_done) *ep_done = true;
         }

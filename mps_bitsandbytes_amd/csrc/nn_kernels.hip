@@ -162,7 +162,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_quantize_rowwise_masked(const T *__restrict__ A, int64_t rows, int64_t cols,
                                                                 const int64_t *__restrict__ oidx, int64_t n_out,
                                                                 int8_t *__restrict__ out, float *__restrict__ scales,
-                                                                T *__restrict__ xo, bool vec_ok) {
+                                                                T *__restrict__ xo, int64_t ldxo, bool vec_ok) {
     // column mask of the outlier set, rebuilt per workgroup in LDS (cols bytes, rounded up to 8): cheaper than a
     // global mask + two extra launches for the handful of outlier columns of a layer
     extern __shared__ __attribute__((aligned(8))) uint8_t mask[];
@@ -205,9 +205,13 @@ __global__ __launch_bounds__(256) void k_quantize_rowwise_masked(const T *__rest
     __syncthreads();
     am = fmaxf(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])), 1e-8f);
     if (threadIdx.x == 0) scales[r] = am;
-    // the row's outlier activations, compact and padded to 16: the GEMM epilogue reads them as one 16-byte fragment
-    if (xo != nullptr && threadIdx.x < 16)
-        xo[r * 16 + threadIdx.x] = (threadIdx.x < n_out) ? row[oidx[threadIdx.x]] : from_f32<T>(0.0f);
+    // the row's outlier activations, compact and zero padded to a multiple of 16 (ldxo): the GEMM epilogue reads them as
+    // 16-byte fragments, one chunk of 16 outliers per MFMA
+    if (xo != nullptr)
+        for (int64_t j = threadIdx.x; j < ldxo; j += 256) {
+            const int64_t c = j < n_out ? oidx[j] : -1;
+            xo[r * ldxo + j] = (c >= 0 && c < cols) ? row[c] : from_f32<T>(0.0f);
+        }
     const float s = rscale127(am);
     int8_t *orow = out + r * cols;
     for (int64_t g = threadIdx.x; g < nvec; g += 256) {
@@ -326,17 +330,26 @@ __global__ __launch_bounds__(256) void k_outlier_add(const T *__restrict__ X, in
     }
 }
 
+// workspace: [x_q int8 M*K | pad to 256][x_scales f32 M | pad to 256][compact outlier activations M x ldx (16-bit types)]
+int64_t outlier_linear_workspace_bytes(int64_t M, int64_t K, int64_t n_out) {
+    const int64_t ldx = ((n_out + 15) / 16) * 16;
+    return ((M * K + 255) & ~(int64_t)255) + ((4 * M + 255) & ~(int64_t)255) + ((2 * ldx * M + 255) & ~(int64_t)255);
+}
+
 template <typename T>
 static int launch_outlier_linear(const void *X, int64_t M, int64_t K, const int8_t *W, const float *w_scales, int64_t N,
                                  const int64_t *oidx, int64_t n_out, const void *ow, const void *bias, void *out,
-                                 void *workspace, int dtype, hipStream_t st) {
-    // workspace: [x_q int8 M*K | pad to 256][x_scales f32 M | pad to 256][outlier activations M x 16 (16-bit types)]
+                                 void *workspace, int64_t ws_bytes, int dtype, hipStream_t st) {
     char *ws = static_cast<char *>(workspace);
     int8_t *xq = reinterpret_cast<int8_t *>(ws);
     const int64_t off_s = (M * K + 255) & ~(int64_t)255;
     float *xs = reinterpret_cast<float *>(ws + off_s);
     const int64_t off_x = off_s + ((4 * M + 255) & ~(int64_t)255);
-    T *xo = (n_out > 0 && n_out <= 16 && sizeof(T) == 2) ? reinterpret_cast<T *>(ws + off_x) : nullptr;
+    // the compact outlier activations exist when the workspace has room for all chunks of 16 (a caller that sized it with
+    // the two-argument query has room for one chunk: more outliers then take the separate k_outlier_add pass)
+    const int64_t ldx = ((n_out + 15) / 16) * 16;
+    const bool room = ws_bytes >= outlier_linear_workspace_bytes(M, K, n_out);
+    T *xo = (n_out > 0 && room && sizeof(T) == 2) ? reinterpret_cast<T *>(ws + off_x) : nullptr;
     const size_t mask_lds = (size_t)((K + 7) & ~(int64_t)7);
     if (mask_lds > 65536) {
         set_error("outlier_linear: in_features %lld too large for the LDS column mask", (long long)K);
@@ -344,12 +357,12 @@ static int launch_outlier_linear(const void *X, int64_t M, int64_t K, const int8
     }
     const bool vec_ok = (K % 8 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
     hipLaunchKernelGGL(k_quantize_rowwise_masked<T>, dim3((unsigned)M), dim3(256), mask_lds, st, static_cast<const T *>(X), M, K,
-                       oidx, n_out, xq, xs, xo, vec_ok);
+                       oidx, n_out, xq, xs, xo, ldx, vec_ok);
     int rc = check_launch("outlier_linear(quantize)");
     if (rc) return rc;
-    // the 256 x 256 kernel folds the outlier columns and the bias into its epilogue (one MFMA per tile and 16 outliers);
-    // the other int8 kernels leave them to k_outlier_add
-    const OutlierEpilogue ep{xo, 16, oidx, n_out, ow, bias};   // x: the compact [M, 16] outlier activations
+    // the 256 x 256 kernel folds the outlier columns (one MFMA per tile and chunk of 16 outliers) and the bias into its
+    // epilogue; the other int8 kernels leave them to k_outlier_add
+    const OutlierEpilogue ep{xo, ldx, oidx, n_out, ow, bias};
     bool fused = false;
     rc = matmul_int8_nt_dispatch(xq, W, xs, w_scales, M, N, K, dtype, out, st, ((n_out == 0 || xo != nullptr) && (n_out > 0 || bias)) ? &ep : nullptr, &fused);
     if (rc) return rc;
@@ -366,11 +379,11 @@ static int launch_outlier_linear(const void *X, int64_t M, int64_t K, const int8
 
 int outlier_linear_dispatch(const void *X, int dtype, int64_t M, int64_t K, const int8_t *W, const float *w_scales, int64_t N,
                             const int64_t *oidx, int64_t n_out, const void *ow, const void *bias, void *out, void *workspace,
-                            hipStream_t st) {
+                            int64_t ws_bytes, hipStream_t st) {
     switch (dtype) {
-        case MBNB_F16: return launch_outlier_linear<f16_t>(X, M, K, W, w_scales, N, oidx, n_out, ow, bias, out, workspace, dtype, st);
-        case MBNB_BF16: return launch_outlier_linear<bf16_t>(X, M, K, W, w_scales, N, oidx, n_out, ow, bias, out, workspace, dtype, st);
-        default: return launch_outlier_linear<float>(X, M, K, W, w_scales, N, oidx, n_out, ow, bias, out, workspace, dtype, st);
+        case MBNB_F16: return launch_outlier_linear<f16_t>(X, M, K, W, w_scales, N, oidx, n_out, ow, bias, out, workspace, ws_bytes, dtype, st);
+        case MBNB_BF16: return launch_outlier_linear<bf16_t>(X, M, K, W, w_scales, N, oidx, n_out, ow, bias, out, workspace, ws_bytes, dtype, st);
+        default: return launch_outlier_linear<float>(X, M, K, W, w_scales, N, oidx, n_out, ow, bias, out, workspace, ws_bytes, dtype, st);
     }
 }
 

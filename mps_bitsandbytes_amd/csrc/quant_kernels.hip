@@ -111,6 +111,25 @@ template <int QT> __device__ __forceinline__ uint32_t nearest_code_lut(float xn,
     }
 }
 
+// absmax of one quantisation block held by a team of `team` consecutive lanes (8 values each): abs().max() with the
+// reference's clamp(min=1e-8) (functional.py:232).  torch's max PROPAGATES NaN (fmaxf drops it): a block that holds a NaN
+// gets a NaN absmax, every x / absmax is then NaN and the threshold count below returns index 0 for all of them -- what
+// argmin over all-NaN distances gives in the reference.
+__device__ __forceinline__ float block_absmax8(const float (&x)[8], int team) {
+    float am = 0.0f, nan = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        am = fmaxf(am, fabsf(x[j]));
+        nan = (x[j] != x[j]) ? 1.0f : nan;
+    }
+    for (int off = 1; off < team; off <<= 1) {
+        am = fmaxf(am, __shfl_xor(am, off, 64));
+        nan = fmaxf(nan, __shfl_xor(nan, off, 64));
+    }
+    am = fmaxf(am, 1e-8f);
+    return nan != 0.0f ? __builtin_bit_cast(float, 0x7FC00000u) : am;
+}
+
 template <typename T, int QT>
 __global__ __launch_bounds__(256) void k_quantize_4bit(const T *__restrict__ A, int64_t rows, int64_t cols,
                                                       int64_t cols_padded, int blocksize,
@@ -154,11 +173,7 @@ __global__ __launch_bounds__(256) void k_quantize_4bit(const T *__restrict__ A, 
         if (absmax_in) {
             am = active ? absmax_in[r * nblk + blk] : 1.0f;
         } else {
-            am = 0.0f;
-#pragma unroll
-            for (int j = 0; j < 8; j++) am = fmaxf(am, fabsf(x[j]));
-            for (int off = 1; off < team; off <<= 1) am = fmaxf(am, __shfl_xor(am, off, 64));
-            am = fmaxf(am, 1e-8f);  // clamp(min=1e-8), functional.py:232
+            am = block_absmax8(x, team);
         }
         if (!active) return;
         if ((lane & (team - 1)) == 0) absmax_out[r * nblk + blk] = am;
@@ -174,13 +189,18 @@ __global__ __launch_bounds__(256) void k_quantize_4bit(const T *__restrict__ A, 
             am = absmax_in[r * nblk + blk];
         } else {
             am = 0.0f;
+            float nan = 0.0f;
             for (int s = 0; s < span; s += 512) {
                 float x[8];
                 load8<T>(A, rows, cols, r, kspan + s + lane * 8, vec_ok, x);
 #pragma unroll
-                for (int j = 0; j < 8; j++) am = fmaxf(am, fabsf(x[j]));
+                for (int j = 0; j < 8; j++) {
+                    am = fmaxf(am, fabsf(x[j]));
+                    nan = (x[j] != x[j]) ? 1.0f : nan;
+                }
             }
             am = fmaxf(wave_max(am), 1e-8f);
+            if (wave_max(nan) != 0.0f) am = __builtin_bit_cast(float, 0x7FC00000u);   // abs().max() propagates NaN
         }
         if (lane == 0) absmax_out[r * nblk + blk] = am;
         for (int s = 0; s < span; s += 512) {
@@ -193,6 +213,57 @@ __global__ __launch_bounds__(256) void k_quantize_4bit(const T *__restrict__ A, 
             *reinterpret_cast<uint32_t *>(packed + (r * cols_padded + k0) / 2) = w;
         }
     }
+}
+
+// quantize_4bit with compress_statistics=True in ONE launch (functional.py:288-292: quantize_blockwise(absmax, 256) right
+// after the 4-bit quantisation): a workgroup owns one GROUP of 256 consecutive quantisation blocks (flat order, the order
+// quantize_blockwise sees), i.e. 256 * blocksize elements walked in steps of 2048; the 256 absmax values stay in LDS and
+// leave as int8 codes + one f32 absmax2 (quantize_blockwise's arithmetic: max|.| clamp 1e-8, rscale127, RNE, clamp) --
+// the f32 absmax never goes to memory.  8 <= blocksize <= 512.
+template <typename T, int QT>
+__global__ __launch_bounds__(256) void k_quantize_4bit_dq(const T *__restrict__ A, int64_t rows, int64_t cols, int64_t cols_padded,
+                                                         int blocksize, uint8_t *__restrict__ packed,
+                                                         int8_t *__restrict__ am_codes, float *__restrict__ absmax2, bool vec_ok) {
+    __shared__ uint8_t s_bins[256];
+    __shared__ float s_thr[16];
+    __shared__ float s_am[256];
+    __shared__ float red[4];
+    fill_code_bins<QT>(s_bins, s_thr, threadIdx.x);
+    __syncthreads();
+    const int tid = threadIdx.x;
+    const int team = blocksize >> 3;                 // lanes per block: 1 .. 64
+    const int bpi = 256 / team;                      // blocks per 2048-element step
+    const int64_t nblk = cols_padded / blocksize, total = rows * nblk;
+    const int64_t b0 = (int64_t)blockIdx.x * 256;
+    const int tb = tid / team, tl = tid - tb * team;
+    for (int it = 0; it < team; it++) {              // 256 / bpi = team steps
+        const int64_t b = b0 + (int64_t)it * bpi + tb;
+        const bool active = b < total;
+        const int64_t bb = active ? b : 0;
+        const int64_t r = bb / nblk, k0 = (bb - r * nblk) * blocksize + (int64_t)tl * 8;
+        float x[8];
+        if (active) load8<T>(A, rows, cols, r, k0, vec_ok, x);
+        else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) x[j] = 0.0f;
+        }
+        const float am = block_absmax8(x, team);
+        if (tl == 0) s_am[it * bpi + tb] = active ? am : 0.0f;
+        if (active) {
+            uint32_t w = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) w |= nearest_code_lut<QT>(x[j] / am, s_bins, s_thr) << (4 * j);
+            *reinterpret_cast<uint32_t *>(packed + (r * cols_padded + k0) / 2) = w;
+        }
+    }
+    __syncthreads();
+    const float v = s_am[tid];
+    float am2 = wave_max(fabsf(v));
+    if ((tid & 63) == 0) red[tid >> 6] = am2;
+    __syncthreads();
+    am2 = fmaxf(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])), 1e-8f);   // functional.py:513-514
+    if (tid == 0) absmax2[blockIdx.x] = am2;
+    if (b0 + tid < total) am_codes[b0 + tid] = quant_i8(v, rscale127(am2));    // functional.py:518-521
 }
 
 // blocksize in {1, 2, 4}: one thread per output byte
@@ -563,6 +634,31 @@ static int launch_quantize_4bit(const void *A, int64_t rows, int64_t cols, int64
         hipLaunchKernelGGL((k_quantize_4bit<T, MBNB_FP4>), grid, dim3(256), 0, st, a, rows, cols, cols_padded,
                            blocksize, absmax_in, packed, absmax_out, vec_ok, row_grid);
     return check_launch("quantize_4bit");
+}
+
+template <typename T>
+static int launch_quantize_4bit_dq(const void *A, int64_t rows, int64_t cols, int64_t cols_padded, int blocksize, int qt,
+                                   uint8_t *packed, int8_t *am_codes, float *absmax2, hipStream_t st) {
+    const T *a = static_cast<const T *>(A);
+    const bool vec_ok = aligned16(A) && (cols % 8 == 0);
+    const int64_t total = rows * (cols_padded / blocksize);
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    if (qt == MBNB_NF4)
+        hipLaunchKernelGGL((k_quantize_4bit_dq<T, MBNB_NF4>), dim3(grid), dim3(256), 0, st, a, rows, cols, cols_padded, blocksize,
+                           packed, am_codes, absmax2, vec_ok);
+    else
+        hipLaunchKernelGGL((k_quantize_4bit_dq<T, MBNB_FP4>), dim3(grid), dim3(256), 0, st, a, rows, cols, cols_padded, blocksize,
+                           packed, am_codes, absmax2, vec_ok);
+    return check_launch("quantize_4bit(dq)");
+}
+
+int quantize_4bit_dq_dispatch(const void *A, int dtype, int64_t rows, int64_t cols, int64_t cols_padded, int blocksize,
+                              int qt, uint8_t *packed, int8_t *am_codes, float *absmax2, hipStream_t st) {
+    switch (dtype) {
+        case MBNB_F16: return launch_quantize_4bit_dq<f16_t>(A, rows, cols, cols_padded, blocksize, qt, packed, am_codes, absmax2, st);
+        case MBNB_BF16: return launch_quantize_4bit_dq<bf16_t>(A, rows, cols, cols_padded, blocksize, qt, packed, am_codes, absmax2, st);
+        default: return launch_quantize_4bit_dq<float>(A, rows, cols, cols_padded, blocksize, qt, packed, am_codes, absmax2, st);
+    }
 }
 
 int quantize_4bit_dispatch(const void *A, int dtype, int64_t rows, int64_t cols, int64_t cols_padded,

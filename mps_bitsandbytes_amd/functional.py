@@ -224,12 +224,27 @@ def quantize_4bit(
         absmax_in = absmax.to(device=A.device, dtype=torch.float32).contiguous().view(-1)
         if absmax_in.numel() != nblocks:
             raise ValueError(f"absmax has {absmax_in.numel()} elements, expected {nblocks}")
-    absmax_out = torch.empty(nblocks, dtype=torch.float32, device=A.device)
-
+    # compress_statistics: the 256-block int8 quantisation of absmax (functional.py:288-292) is fused into the same launch
+    # when the library supports the blocksize; the f32 absmax then never exists in memory
+    fused_dq = compress_statistics and absmax_in is None and 8 <= blocksize <= 512 and nblocks > 0
+    absmax_t = None
+    state2 = None
     with torch.cuda.device(A.device):
-        check(_native.lib().mbnb_quantize_4bit(
-            ptr(A), code, rows, cols, cols_padded, int(blocksize), _native.QUANT_CODE[quant_type],
-            ptr(absmax_in), ptr(packed), ptr(absmax_out), stream_ptr(A.device)), "quantize_4bit")
+        if fused_dq:
+            codes = torch.empty(nblocks, dtype=torch.int8, device=A.device)
+            absmax2 = torch.empty((nblocks + 255) // 256, dtype=torch.float32, device=A.device)
+            check(_native.lib().mbnb_quantize_4bit_dq(
+                ptr(A), code, rows, cols, cols_padded, int(blocksize), _native.QUANT_CODE[quant_type], ptr(packed),
+                ptr(codes), ptr(absmax2), stream_ptr(A.device)), "quantize_4bit")
+            absmax_t = codes
+            state2 = QuantState(absmax=absmax2, shape=torch.Size([nblocks]), blocksize=256, quant_type="int8",
+                                dtype=torch.float32)     # = what quantize_blockwise(absmax, blocksize=256) returns
+        else:
+            absmax_out = torch.empty(nblocks, dtype=torch.float32, device=A.device)
+            check(_native.lib().mbnb_quantize_4bit(
+                ptr(A), code, rows, cols, cols_padded, int(blocksize), _native.QUANT_CODE[quant_type],
+                ptr(absmax_in), ptr(packed), ptr(absmax_out), stream_ptr(A.device)), "quantize_4bit")
+            absmax_t = absmax_out
 
     if user_out is not None and packed.data_ptr() != user_out.data_ptr():
         user_out.view(-1)[:] = packed.to(user_out.dtype)  # reference: out[:] = ... (functional.py:251)
@@ -237,10 +252,8 @@ def quantize_4bit(
     elif quant_storage != torch.uint8:
         packed = packed.to(quant_storage)
 
-    absmax_t = absmax_out
-    state2 = None
-    if compress_statistics:
-        absmax_t, state2 = quantize_blockwise(absmax_out, blocksize=256)
+    if compress_statistics and not fused_dq:
+        absmax_t, state2 = quantize_blockwise(absmax_t, blocksize=256)
 
     quant_state = QuantState(
         absmax=absmax_t,
@@ -752,10 +765,11 @@ def outlier_linear(input: Tensor, weight_int8: Tensor, weight_scales: Tensor, ou
     ow = outlier_weights.to(device=dev, dtype=dtype).contiguous() if n_out else None
     b = None if bias is None else bias.to(device=dev, dtype=dtype).contiguous()
     out = torch.empty(M, N, dtype=dtype, device=dev)
-    ws = torch.empty(int(_native.lib().mbnb_outlier_linear_workspace_bytes(M, K)), dtype=torch.uint8, device=dev)
+    ws_bytes = int(_native.lib().mbnb_outlier_linear_workspace_bytes_n(M, K, n_out))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
-        check(_native.lib().mbnb_outlier_linear(ptr(x), dcode, M, K, ptr(w), ptr(s), N, ptr(oi), n_out, ptr(ow), ptr(b),
-                                                ptr(out), ptr(ws), stream_ptr(dev)), "outlier_linear")
+        check(_native.lib().mbnb_outlier_linear_ws(ptr(x), dcode, M, K, ptr(w), ptr(s), N, ptr(oi), n_out, ptr(ow), ptr(b),
+                                                   ptr(out), ptr(ws), ws_bytes, stream_ptr(dev)), "outlier_linear")
     return out.reshape(*input.shape[:-1], N)
 
 

@@ -152,12 +152,17 @@ int orc_quantize_4bit(const void *A, int dtype, int64_t rows, int64_t cols, int6
                 am = absmax_in[r * nblk + b];
             } else {
                 am = 0.0f;
+                int has_nan = 0;
                 for (int j = 0; j < blocksize; j++) {
                     int64_t k = k0 + j;
                     float v = (k < cols) ? fabsf(load_elem(A, dtype, r * cols + k)) : 0.0f;
+                    if (v != v) has_nan = 1;
                     if (v > am) am = v;
                 }
                 if (am < 1e-8f) am = 1e-8f;
+                /* torch's abs().max() propagates NaN (and clamp keeps it): functional.py:231-232.  The distances below
+                 * are then all NaN, `d < bestd` is never true, and the index stays 0 -- torch.argmin's answer too. */
+                if (has_nan) am = NAN;
             }
             absmax_out[r * nblk + b] = am;
             for (int j = 0; j < blocksize; j++) {

@@ -28,7 +28,22 @@ from mps_bitsandbytes_amd import synthetic  # noqa: E402
 
 
 def main():
-    arrays, manifest = {}, {"dequant_absmax": [], "config_from_dict": []}
+    arrays, manifest = {}, {"dequant_absmax": [], "config_from_dict": [], "quant4_nan": []}
+    # NaN inside a quantisation block: the reference's abs().max() propagates it into absmax and argmin over
+    # all-NaN distances returns index 0 for the whole block; neighbouring blocks are untouched
+    for i, (dt, qt, bs, shape) in enumerate([(torch.float16, "nf4", 64, (4, 256)), (torch.float32, "fp4", 64, (3, 192)),
+                                             (torch.bfloat16, "nf4", 32, (2, 128)), (torch.float16, "nf4", 1024, (1, 2048))]):
+        x = synthetic.normal(shape, dt, seed=400 + i)
+        xf = x.view(-1)
+        for pos in (5, (shape[1] + 70) % xf.numel(), xf.numel() - 3):
+            xf[pos] = float("nan")
+        packed, st = ref.functional.quantize_4bit(x.clone(), blocksize=bs, quant_type=qt)
+        k = f"qn{i}_"
+        arrays[k + "x"] = x.view(torch.int16).numpy().view(np.uint16) if dt != torch.float32 else x.numpy().view(np.uint32)
+        arrays[k + "packed"] = packed.numpy()
+        arrays[k + "absmax"] = st.absmax.float().contiguous().numpy().view(np.uint32)
+        manifest["quant4_nan"].append({"id": i, "dtype": {torch.float16: "f16", torch.bfloat16: "bf16", torch.float32: "f32"}[dt],
+                                       "quant_type": qt, "blocksize": bs, "shape": list(shape)})
     cases = [
         dict(rows=4, num_blocks=600, dq_blocks=3, blocksize=256, code="int8"),     # ragged last block (88 codes)
         dict(rows=3, num_blocks=512, dq_blocks=2, blocksize=256, code="uint8"),

@@ -129,9 +129,12 @@ def test_outlier_linear_golden(g6):
 
 
 @pytest.mark.parametrize("M,K,N,dt,n_out,bias", [(512, 4096, 4096, torch.float16, 12, True), (300, 1024, 777, torch.bfloat16, 0, True),
-                                                  (64, 200, 96, torch.float16, 3, False), (2048, 4096, 4096, torch.bfloat16, 40, False)])
+                                                  (64, 200, 96, torch.float16, 3, False), (2048, 4096, 4096, torch.bfloat16, 40, False),
+                                                  (2560, 512, 2560, torch.float16, 21, True), (2600, 256, 2500, torch.bfloat16, 64, True)])
 def test_outlier_linear_vs_oracle(M, K, N, dt, n_out, bias):
-    """MFMA-sized shapes (256^2 and 128^2 int8 kernels), ragged K (generic kernel), with / without outliers and bias."""
+    """MFMA-sized shapes (256^2 and 128^2 int8 kernels), ragged K (generic kernel), with / without outliers and bias; on the
+    256^2 kernel the outlier columns ride in the epilogue in chunks of 16 (12, 21, 40 and 64 columns: one to four chunks,
+    ragged last chunk, weight rows not 16-byte aligned at 21)."""
     W = synthetic.normal((N, K), torch.float32, seed=821, std=0.05)
     oidx = torch.from_numpy(np.sort((synthetic.uniform_u64(4 * n_out + 1, seed=822) % np.uint64(K)).astype(np.int64))).unique()[:n_out]
     W[:, oidx] *= 30.0

@@ -763,3 +763,33 @@ def test_quant_state_from_dict_with_cpu_state2_and_mismatched_absmax():
                                           quant_type="int8", dtype=torch.float32))
     with pytest.raises(ValueError, match="state2.absmax has"):
         bnb.matmul_4bit(X, packed, short2)
+
+
+def test_quantize_4bit_nan_blocks_match_the_reference():
+    """a NaN inside a block -> NaN absmax and index 0 for the whole block (reference: abs().max() propagates
+    NaN, argmin over all-NaN distances is 0); goldens produced by the reference (g8_misc.npz)."""
+    from tests.test_oracle_misc_golden import check_quant4_nan
+
+    def q(x, bs, qt):
+        packed, st = bnb.quantize_4bit(x.to(DEV), blocksize=bs, quant_type=qt)
+        return packed, st.absmax
+    check_quant4_nan(q)
+
+
+@pytest.mark.parametrize("bs", [8, 16, 64, 128, 512, 1024])
+def test_quantize_4bit_fused_double_quant_equals_two_launches(bs):
+    """compress_statistics=True in one launch (mbnb_quantize_4bit_dq, 8 <= blocksize <= 512) must give exactly what
+    quantize_4bit followed by quantize_blockwise(absmax, 256) gives (functional.py:288-292) -- packed bytes, int8 absmax
+    codes, absmax2 -- on ragged shapes, flat tensors and groups of 256 blocks that straddle rows."""
+    for shape, dt in (((300, 1000), torch.float16), ((7, 4160), torch.bfloat16), ((5000,), torch.float32), ((1, 64), torch.float16),
+                      ((513, 512), torch.bfloat16)):
+        x = synthetic.normal(shape, dt, seed=77 + bs).to(DEV)
+        p1, s1 = bnb.quantize_4bit(x, blocksize=bs, compress_statistics=True)
+        p0, s0 = bnb.quantize_4bit(x, blocksize=bs, compress_statistics=False)
+        q0, st0 = bnb.quantize_blockwise(s0.absmax, blocksize=256)
+        assert torch.equal(p1, p0), (shape, bs)
+        assert s1.absmax.dtype == torch.int8 and torch.equal(s1.absmax, q0), (shape, bs)
+        assert bits_equal(s1.state2.absmax, st0.absmax) and s1.state2.blocksize == 256 and s1.state2.dtype == torch.float32
+        assert tuple(s1.state2.shape) == tuple(st0.shape) and s1.state2.quant_type == "int8"
+        assert torch.equal(bnb.dequantize_4bit(p1, s1), bnb.dequantize_4bit(p0, QuantState(
+            absmax=q0, shape=s0.shape, blocksize=bs, quant_type="nf4", dtype=dt, state2=st0)))

@@ -34,3 +34,24 @@ def test_config_from_dict_string_dtype_matches_reference():
     for rec in MAN["config_from_dict"]:
         cfg = bnb.BitsAndBytesConfig.from_dict({"load_in_4bit": True, "bnb_4bit_compute_dtype": rec["in"]})
         assert str(cfg.bnb_4bit_compute_dtype) == rec["out"], rec
+
+
+def check_quant4_nan(quantize):
+    """quantize(x, blocksize, quant_type) -> (packed u8, absmax f32), compared with the reference's outputs: packed bytes
+    bit-exact (a block holding a NaN gets index 0 throughout), absmax NaN exactly where the reference's is."""
+    from tests.goldenio import DT
+    npz = np.load(os.path.join(HERE, "g8_misc.npz"))
+    for c in MAN["quant4_nan"]:
+        k = f"qn{c['id']}_"
+        x = from_bits(npz[k + "x"], DT[c["dtype"]]).reshape(c["shape"])
+        packed, absmax = quantize(x, c["blocksize"], c["quant_type"])
+        g_packed, g_absmax = torch.from_numpy(np.ascontiguousarray(npz[k + "packed"])), from_bits(npz[k + "absmax"])
+        nan = torch.isnan(g_absmax)
+        assert int(nan.sum()) >= 2, c
+        assert torch.equal(packed.cpu().view(-1), g_packed.view(-1)), c
+        a = absmax.cpu().view(-1)
+        assert torch.equal(torch.isnan(a), nan) and torch.equal(a[~nan].view(torch.int32), g_absmax[~nan].view(torch.int32)), c
+
+
+def test_oracle_quantize_4bit_propagates_nan_like_the_reference():
+    check_quant4_nan(lambda x, bs, qt: oracle.quantize_4bit(x, bs, qt)[:2])
