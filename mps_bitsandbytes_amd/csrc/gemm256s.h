@@ -38,7 +38,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm256s(const T *__restrict__ X, ty
                                                      const T *__restrict__ bias, void *__restrict__ out_v, int out_dtype,
                                                      int64_t M, int64_t N, int64_t K) {
     using Frag = typename Mfma<T>::frag;
-    constexpr bool RAW2 = (VAR & 1) != 0, STAG = (VAR & 2) != 0, ADMA = (VAR & 4) != 0;
+    constexpr bool RAW2 = (VAR & 1) != 0, STAG = (VAR & 2) != 0, ADMA = (VAR & 4) != 0, RFIRST = (VAR & 8) != 0;
     constexpr int AMN = NESTED ? 2 : 1;                     // LDS-DMA instructions of one absmax-by-4 fetch
     constexpr int P_AM4 = P_RAW + 16384;
     constexpr int AM4_SLOT = NESTED ? 2048 : 4096;
@@ -311,10 +311,14 @@ __global__ __launch_bounds__(512, 2) void k_gemm256s(const T *__restrict__ X, ty
             lookup_q(rw[Nn][2], La);
             lookup_q(rw[Nn][3], Lb);
         }
+        if constexpr (RFIRST && ROLE == 0) {
+            lookup_q(rw[Nn][1], Lb);
+            __builtin_amdgcn_sched_barrier(0);   // every LDS read of the group is issued before its first MFMA
+        }
         mfma_group(wfA, xfA);
         if constexpr (ROLE == 0) {
             finish_q(La, ram[Nn], 0, Nn);
-            lookup_q(rw[Nn][1], Lb);
+            if constexpr (!RFIRST) lookup_q(rw[Nn][1], Lb);
         } else if constexpr (ROLE == 1) {
             finish_q(La, ram[Nn], 2, Nn);
             finish_q(Lb, ram[Nn], 3, Nn);
@@ -327,11 +331,18 @@ __global__ __launch_bounds__(512, 2) void k_gemm256s(const T *__restrict__ X, ty
             lookup_q(rw[Nn][0], La);
             lookup_q(rw[Nn][1], Lb);
         }
+        if constexpr (RFIRST && ROLE == 0) {
+            lookup_q(rw[Nn][2], La);
+            lookup_q(rw[Nn][3], Lc);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         mfma_group(wfB, xfB);
         if constexpr (ROLE == 0) {
             finish_q(Lb, ram[Nn], 1, Nn);
-            lookup_q(rw[Nn][2], La);
-            lookup_q(rw[Nn][3], Lc);
+            if constexpr (!RFIRST) {
+                lookup_q(rw[Nn][2], La);
+                lookup_q(rw[Nn][3], Lc);
+            }
         } else if constexpr (ROLE == 2) {
             finish_q(La, ram[Nn], 0, Nn);
             finish_q(Lb, ram[Nn], 1, Nn);
@@ -351,6 +362,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm256s(const T *__restrict__ X, ty
             lookup_q(rw[Nn][2], La);
             lookup_q(rw[Nn][3], Lb);
         }
+        if constexpr (RFIRST) __builtin_amdgcn_sched_barrier(0);
         mfma_group(wfA, xfA);
         if constexpr (ROLE == 0) {
             finish_q(La, ram[Nn], 2, Nn);
@@ -387,9 +399,13 @@ __global__ __launch_bounds__(512, 2) void k_gemm256s(const T *__restrict__ X, ty
             lookup_q(rw[C][0], La);
             lookup_q(rw[C][1], Lb);
         }
+        if constexpr (RFIRST && ROLE == 0) {
+            lookup_q(rw[C][0], La);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         mfma_group(wfB, xfB);
         if constexpr (ROLE == 0) {
-            lookup_q(rw[C][0], La);
+            if constexpr (!RFIRST) lookup_q(rw[C][0], La);
         } else if constexpr (ROLE == 1) {
             finish_q(La, ram[C], 0, C);
             finish_q(Lb, ram[C], 1, C);

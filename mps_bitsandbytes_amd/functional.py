@@ -59,6 +59,16 @@ def _check_device(tensor: Tensor, operation: str = "operation"):
         )
 
 
+_warned: set = set()
+
+
+def _warn_once(key: str, message: str) -> None:
+    if key not in _warned:
+        _warned.add(key)
+        import warnings
+        warnings.warn(message, RuntimeWarning, stacklevel=3)
+
+
 def _padded(n: int, blocksize: int) -> int:
     """K_padded rule, reference functional.py:219-221 / :260-262."""
     p = ((n + blocksize - 1) // blocksize) * blocksize
@@ -526,6 +536,13 @@ def matmul_4bit(
         raise ValueError(f"packed weight has {packed.numel()} bytes, expected {N * K_weight // 2}")
     _check_absmax_count(quant_state.absmax, N, K_weight, blocksize, "matmul_4bit")
 
+    if M * N * K >= (1 << 27) and (w_dtype == torch.float32 or blocksize < 32 or K % 8 != 0):
+        # the MFMA / weight-streaming kernels need a 16-bit QuantState.dtype, blocksize >= 32 and K % 8 == 0; anything else
+        # runs on the generic one-wave-per-output-column kernel, orders of magnitude slower at this size
+        _warn_once("matmul_4bit.generic",
+                   f"matmul_4bit: weight dtype {w_dtype}, blocksize {blocksize}, K {K} takes the generic (non-MFMA) kernel; "
+                   f"quantize a float16 / bfloat16 weight with blocksize >= 32 and K % 8 == 0 for the fast paths "
+                   f"(e.g. Linear4bit.from_linear(linear.to(torch.bfloat16)))")
     out_dtype = compute_dtype if compute_dtype in _native.DTYPE_CODE else w_dtype
     out = torch.empty(M, N, dtype=out_dtype, device=A.device)
     keep: list = []

@@ -383,9 +383,13 @@ def test_g5_matmul_int8_and_linear8bit(golden):
         out = bnb.matmul_int8(from_bits(npz[k + "A"]).to(DEV), from_bits(npz[k + "B"]).to(DEV),
                               from_bits(npz[k + "As"]).to(DEV), from_bits(npz[k + "Bs"]).to(DEV), DT[c["dtype"]])
         ref = from_bits(npz[k + "out"], DT[c["dtype"]]).reshape(c["M"], c["N"])
-        # int32-exact contraction vs the reference's GEMM of dtype-rounded operands (3.6e-4 for fp16)
-        tol = {"f16": 1e-3, "bf16": 8e-3, "f32": 1e-5}[c["dtype"]]
-        assert rel_fro(out, ref) <= tol, (k, rel_fro(out, ref), _native.last_kernel())
+        # int32-exact contraction vs the reference's GEMM of dtype-rounded operands.  Measured on these goldens (exact
+        # formula in f64 vs the reference's stored outputs): 3.7e-4 / 3.8e-4 (fp16), 3.17e-3 (bf16), 2.7e-7 (f32); the
+        # regression gates are measured x 1.5, the hard budget (BASELINE) is 1e-2.
+        tol = {"f16": 6e-4, "bf16": 4.8e-3, "f32": 4e-7}[c["dtype"]]
+        err = rel_fro(out, ref)
+        print(f"matmul_int8 golden {k} ({c['dtype']}): rel-err vs reference {err:.3e} (gate {tol:.1e}, budget {HARD_TOL:.0e})")
+        assert err <= tol and err <= HARD_TOL, (k, err, _native.last_kernel())
     for c in [c for c in golden.manifest["g5"] if c["kind"] == "linear8bit"]:
         k = f"l8{c['id']}_"
         dt = DT[c["dtype"]]

@@ -57,7 +57,7 @@ for name in ("fetch", "write", "tcc", "sq", "lds"):
         continue
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(files[0])):
-        if "k_gemm256p" in r["Kernel_Name"]:
+        if "k_gemm256s" in r["Kernel_Name"] or "k_gemm256p" in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
             if name == "sq" and r["Counter_Name"] == "SQ_WAVE_CYCLES":
                 dur.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
@@ -66,7 +66,7 @@ for name in ("fetch", "write", "tcc", "sq", "lds"):
 if "FETCH_SIZE" in res:
     fetch, write = res["FETCH_SIZE"]["mean"], res["WRITE_SIZE"]["mean"]
     out = {
-        "kernel": "k_gemm256p<bf16, plain absmax> (mfma256), M=N=K=4096, NF4 bs64",
+        "kernel": "k_gemm256s<bf16, plain absmax, RAW2> (mfma256), M=N=K=4096, NF4 bs64",
         "source": "rocprofv3 --kernel-trace --pmc <set> -- python3 bench.py --no-cpu-baseline --no-gemv --steps 5 --warmup 3; "
                   "separate passes: FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum | SQ_* | SQ_LDS_*",
         "gfx950_correction": "FETCH_SIZE counts 64 B per 128-B request on wide coalesced reads: doubled (MI355X_MICROARCH.md, HBM)",

@@ -47,6 +47,9 @@ extern "C" int exp_gemm256(int variant, const void *X, const uint8_t *packed, co
         case 5: return run_s<5>(x, wp, out, M, N, K, st);
         case 6: return run_s<6>(x, wp, out, M, N, K, st);
         case 7: return run_s<7>(x, wp, out, M, N, K, st);
+        case 9: return run_s<9>(x, wp, out, M, N, K, st);
+        case 12: return run_s<12>(x, wp, out, M, N, K, st);
+        case 13: return run_s<13>(x, wp, out, M, N, K, st);
         default: return -1;
     }
 }
