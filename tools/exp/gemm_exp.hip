@@ -4,6 +4,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include "../../mps_bitsandbytes_amd/csrc/gemm256s.h"
+#include "gemm256t.h"
 
 namespace mbnb {
 void set_error(const char *, ...) {}
@@ -32,6 +33,15 @@ extern "C" int exp_gemm256(int variant, const void *X, const uint8_t *packed, co
     if (variant < 0) {
         auto kern = k_gemm256p<bf16_t, false, 0, true, true>;
         constexpr int lds = gemm256p_lds_bytes<false>();
+        static bool done = false;
+        if (!done) { if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return -2; done = true; }
+        const int64_t tiles = ((M + 255) / 256) * ((N + 255) / 256);
+        hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(512), lds, st, x, wp, (const bf16_t *)nullptr, out, (int)MBNB_BF16, M, N, K);
+        return (int)hipGetLastError();
+    }
+    if (variant == 100) {
+        auto kern = k_gemm256t<bf16_t, false>;
+        constexpr int lds = gemm256s_lds_bytes<false, 1>();
         static bool done = false;
         if (!done) { if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return -2; done = true; }
         const int64_t tiles = ((M + 255) / 256) * ((N + 255) / 256);
