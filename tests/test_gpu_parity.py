@@ -797,3 +797,63 @@ def test_quantize_4bit_fused_double_quant_equals_two_launches(bs):
         assert tuple(s1.state2.shape) == tuple(st0.shape) and s1.state2.quant_type == "int8"
         assert torch.equal(bnb.dequantize_4bit(p1, s1), bnb.dequantize_4bit(p0, QuantState(
             absmax=q0, shape=s0.shape, blocksize=bs, quant_type="nf4", dtype=dt, state2=st0)))
+
+
+def test_reentrancy_two_threads_two_streams():
+    """SURVEY 8b threading / streams: the C ABI keeps no per-call state (workspaces travel as arguments, the error text and
+    the kernel name are thread-local), so two host threads driving different streams concurrently must get the results of
+    a serial run -- across every kernel family that needs a dynamic-LDS attribute or a split-K workspace."""
+    import threading
+    N, K = 2560, 512
+    W = synthetic.normal((N, K), torch.bfloat16, seed=301).to(DEV)
+    packed, st = bnb.quantize_nf4(W)
+    Ms = [1, 24, 100, 300, 2560]
+    xs = [synthetic.normal((m, K), torch.bfloat16, seed=302 + m).to(DEV) for m in Ms]
+    want = [bnb.matmul_4bit(x, packed, st) for x in xs]
+    torch.cuda.synchronize()
+    got = {0: None, 1: None}
+    errs = []
+
+    def worker(tid):
+        try:
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                outs = None
+                for _ in range(20):
+                    outs = [bnb.matmul_4bit(x, packed, st) for x in (xs if tid == 0 else xs[::-1])]
+                s.synchronize()
+            got[tid] = outs if tid == 0 else outs[::-1]
+        except Exception as e:   # noqa: BLE001
+            errs.append(repr(e))
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    for tid in (0, 1):
+        for w, g_ in zip(want, got[tid]):
+            assert torch.equal(w, g_)
+
+
+def test_matmul_4bit_inside_a_hip_graph():
+    """The hot path is capturable: no allocation, synchronisation or host round trip inside the library (the workspace of
+    the split-K shapes comes from torch's graph-private pool); replays reproduce the eager result."""
+    N, K = 4096, 1024
+    W = synthetic.normal((N, K), torch.float16, seed=311).to(DEV)
+    packed, st = bnb.quantize_nf4(W, compress_statistics=True)
+    for M in (1, 16, 128, 4096):
+        x = synthetic.normal((M, K), torch.float16, seed=312 + M).to(DEV)
+        eager = bnb.matmul_4bit(x, packed, st)
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            bnb.matmul_4bit(x, packed, st)
+            with torch.cuda.graph(g, stream=side):
+                y = bnb.matmul_4bit(x, packed, st)
+        torch.cuda.current_stream().wait_stream(side)
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(y, eager), M
