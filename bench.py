@@ -701,9 +701,26 @@ def main():
                 dst.copy_(src)
                 copy_ms = min(event_time_ms(lambda: dst.copy_(src), 10) for _ in range(3))
                 del src, dst
+                # what the matrix pipe sustains on THIS box: a bare bf16 MFMA loop on every SIMD (mbnb_probe_mfma); the
+                # spec peak assumes 2.4 GHz, the chip holds much less under MFMA load
+                sink = torch.zeros(1, dtype=torch.float32, device=dev)
+                stp = torch.cuda.current_stream().cuda_stream
+                lib = _native.lib()
+                lib.mbnb_probe_mfma(0, 2000, sink.data_ptr(), stp)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                n_mfma = 0
+                for _ in range(10):
+                    n_mfma += int(lib.mbnb_probe_mfma(0, 20000, sink.data_ptr(), stp))
+                e1.record()
+                e1.synchronize()
+                mfma_tflops = n_mfma * 32768.0 / (e0.elapsed_time(e1) * 1e-3) / 1e12 if n_mfma > 0 else None   # 2*32*32*16 flop per MFMA
                 out["roofline"]["empirical"] = {
                     "vendor_blas_bf16_same_shape_tflops": round(2.0 * M * N * K / (blas_ms * 1e-3) / 1e12, 1),
                     "vendor_blas_us": round(blas_ms * 1e3, 1),
+                    "bare_mfma_loop_bf16_tflops": None if mfma_tflops is None else round(mfma_tflops, 1),
+                    "bare_mfma_note": "v_mfma_f32_32x32x16_bf16 back to back on every SIMD, nothing else: the sustained matrix rate at the clock the chip holds under MFMA load",
                     "dtod_copy_gbs_read_plus_write": round(2.0 * (1 << 30) / (copy_ms * 1e-3) / 1e9, 0)}
             except Exception as e:  # context only: never fails the bench
                 out["roofline"]["empirical"] = {"error": str(e)[:200]}

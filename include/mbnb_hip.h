@@ -55,6 +55,13 @@ const char *mbnb_last_error(void);
  * dispatched to ("gemv", "mfma128", "generic", ...) — for tests and the bench driver */
 const char *mbnb_last_kernel(void);
 
+/* Measurement aid (bench.py `roofline.empirical`; not part of the reference boundary): launches a bare MFMA loop -- one wave
+ * per SIMD on 256 workgroups, four independent accumulators, `iters` iterations of four v_mfma_f32_32x32x16_bf16 (kind 0) or
+ * v_mfma_i32_32x32x32_i8 (kind 1) -- on `stream` and returns the number of MFMA wave-instructions issued (> 0), or a status
+ * (<= 0 / hipError_t) on failure.  The caller times it: sustained rate = return value * 32768 (bf16) or 65536 (i8) ops / time.
+ * `sink`: 4 device bytes, never written in practice. */
+int64_t mbnb_probe_mfma(int kind, int iters, float *sink, void *stream);
+
 /* ---------------------------------------------------------------------------
  * Absmax descriptor used by the 4-bit consumers.  Either plain f32 absmax
  * (absmax_i8 == NULL), or the reference's "double quantised" form

@@ -37,6 +37,7 @@ _SIGNATURES = {
     "mbnb_abi_version": (c_int, []),
     "mbnb_last_error": (c_char_p, []),
     "mbnb_last_kernel": (c_char_p, []),
+    "mbnb_probe_mfma": (c_int64, [c_int, c_int, c_void_p, c_void_p]),
     "mbnb_quantize_4bit": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_int, c_int, c_void_p,
                                    c_void_p, c_void_p, c_void_p]),
     "mbnb_quantize_4bit_dq": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p,

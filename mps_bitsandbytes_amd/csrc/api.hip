@@ -69,6 +69,7 @@ int quantize_fp8_dispatch(const void *, int, int64_t, int64_t, uint8_t *, float 
 int dequantize_fp8_dispatch(const uint8_t *, const float *, int64_t, int64_t, int, void *, hipStream_t);
 int linear_fp8_dispatch(const void *, int, int64_t, int64_t, const uint8_t *, const float *, int64_t, const void *, void *, void *, int64_t, hipStream_t);
 int64_t matmul4_splitk_slices(int64_t, int64_t, int64_t);
+int probe_mfma_dispatch(int, int, float *, hipStream_t);
 int64_t gemm_mid_workspace_bytes(int64_t, int64_t, int64_t);
 int matmul_int8_dispatch(const int8_t *, const int8_t *, const float *, const float *, int64_t, int64_t, int64_t, int, void *, void *, hipStream_t);
 int64_t matmul_int8_workspace_bytes(int64_t, int64_t, int64_t);
@@ -110,6 +111,13 @@ using namespace mbnb;
 extern "C" {
 
 int mbnb_abi_version(void) { return MBNB_ABI_VERSION; }
+
+int64_t mbnb_probe_mfma(int kind, int iters, float *sink, void *stream) {
+    if ((kind != 0 && kind != 1) || iters <= 0 || !sink) return fail(MBNB_ERR_ARG, "probe_mfma: bad argument");
+    if (int rc = probe_mfma_dispatch(kind, iters, sink, static_cast<hipStream_t>(stream))) return rc;
+    // matrix operations issued by the launch: 256 workgroups x 4 waves x 4 MFMAs per iteration
+    return (int64_t)256 * 4 * 4 * iters;
+}
 const char *mbnb_last_error(void) { return g_err; }
 const char *mbnb_last_kernel(void) { return g_kernel; }
 
