@@ -588,6 +588,47 @@ def main():
                            "frac": round(kern_tflops / peak, 4), "traffic": traffic.get(tkey) if tkey else None,
                            "kernel_us": round(kern_ms * 1e3, 2),
                            "kernel_us_note": "HIP events around the K launches of the median repetition / K (includes the inter-launch boundary)"}
+        if kernel_name.startswith("dequant+dense") and wl in ("nf4_m4096", "nf4dq_ffn"):
+            # A step is two launches here: dequantize_4bit into the scratch, then k_gemm_dense.  The roofline object is the
+            # DOMINANT kernel's: k_gemm_dense timed on its own (same operands, same stream, events around K launches), with
+            # the dequantise pass and the whole step beside it.
+            lib, code, sp = _native.lib(), _native.DTYPE_CODE[dt], _native.stream_ptr(dev)
+            Wd = bnb.dequantize_4bit(packed, state)
+            Yd = torch.empty(M, N, dtype=dt, device=dev)
+            st_ = torch.cuda.current_stream()
+
+            def dense_only():
+                rc = lib.mbnb_gemm_dense(X.data_ptr(), Wd.data_ptr(), code, None, code, Yd.data_ptr(), M, N, K, K, None, 0, 1, sp)
+                if rc != 0:
+                    raise RuntimeError(f"mbnb_gemm_dense: {rc}")
+
+            def dequant_only():
+                bnb.dequantize_4bit(packed, state, out=Wd)
+
+            def ev_us(fn):
+                vals = []
+                for _ in range(reps_n):
+                    for _ in range(3):
+                        fn()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(st_)
+                    for _ in range(args.steps):
+                        fn()
+                    e1.record(st_)
+                    e1.synchronize()
+                    vals.append(e0.elapsed_time(e1) / args.steps * 1e3)
+                return sorted(vals)[len(vals) // 2]
+
+            dense_us, deq_us = ev_us(dense_only), ev_us(dequant_only)
+            assert torch.equal(Yd, bnb.matmul_4bit(X, packed, state)), "dense-only launch differs from the step's output"
+            d_tflops = flops_per_step / (dense_us * 1e-6) / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": "k_gemm_dense", "achieved": round(d_tflops, 2), "peak": peak, "unit": "TFLOP/s",
+                               "frac": round(d_tflops / peak, 4), "traffic": traffic.get("k_gemm_dense_bytes_per_launch"),
+                               "kernel_us": round(dense_us, 2),
+                               "kernel_us_note": "k_gemm_dense alone: HIP events around K launches on the launching stream / K, median repetition",
+                               "step_us": round(kern_ms * 1e3, 2), "dequantize_us": round(deq_us, 2),
+                               "step_frac": round(kern_tflops / peak, 4),
+                               "step_note": "a step = dequantize_4bit into the scratch + k_gemm_dense; step_frac = algorithmic flops / step_us / peak"}
 
     if args.verify and do_gather:
         # gathered == unsharded: rank 0 rebuilds every rank's rows and runs the whole batch through the same kernel

@@ -165,6 +165,18 @@ int mbnb_matmul_4bit(const void *A, int64_t M, int64_t K, const uint8_t *packed,
  * slices whose f32 partial sums are added in slice order (deterministic) before the bias and the rounding.
  * Same results contract as mbnb_matmul_4bit; workspace == NULL behaves exactly like it. */
 int64_t mbnb_matmul_4bit_workspace_bytes(int64_t M, int64_t N, int64_t K);
+/* The same query for a weight whose rows are padded to K_weight > K columns (QuantState of a K that is not a multiple of
+ * the blocksize; functional.py:216-223); mbnb_matmul_4bit_workspace_bytes(M, N, K) is this with K_weight = K.
+ * Large M (>= 512 rows, K % 64 == 0, 16-bit weight dtype): the workspace also holds the weight dequantised ONCE,
+ * [N, K_weight] in the weight dtype (256-byte aligned; the bits mbnb_dequantize_4bit writes), and the product runs as a
+ * dense 256 x 256 MFMA GEMM on it (csrc/gemm_dense.h) -- the fused kernels decode every weight tile once per 256 rows of A,
+ * which at M = 4096 is 16 decodes of the same weight.  The reference's own large-batch path is the same two steps
+ * (functional.py:753-767, "used for M > 512": dequantize_4bit, then F.linear).  A workspace shorter than the query costs the fast path, never
+ * the result. */
+int64_t mbnb_matmul_4bit_workspace_bytes_kw(int64_t M, int64_t N, int64_t K, int64_t K_weight);
+/* The split-K share of that query alone: a caller that cannot spare N x K_weight x 2 bytes passes a workspace of this size
+ * and keeps the fused dequant + MFMA kernels at every M (0 = no split needed). */
+int64_t mbnb_matmul_4bit_splitk_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int mbnb_matmul_4bit_ws(const void *A, int64_t M, int64_t K, const uint8_t *packed,
                         const mbnb_absmax *absmax, int64_t N, int64_t K_weight, int blocksize,
                         int quant_type, int w_dtype, const void *bias, int out_dtype, void *out,
@@ -185,6 +197,24 @@ int mbnb_matmul_int8(const int8_t *A, const int8_t *B, const float *A_scales,
                      const float *B_scales, int64_t M, int64_t N, int64_t K, int out_dtype,
                      void *out, void *workspace, void *stream);
 
+/* mbnb_matmul_4bit_ws with a flags word.  MBNB_MATMUL_FUSED_ONLY keeps the fused dequant + MFMA kernels at every M even when
+ * the workspace could hold the dequantised weight (the workspace then serves split-K only); 0 = mbnb_matmul_4bit_ws. */
+#define MBNB_MATMUL_FUSED_ONLY 1
+int mbnb_matmul_4bit_ex(const void *A, int64_t M, int64_t K, const uint8_t *packed,
+                        const mbnb_absmax *absmax, int64_t N, int64_t K_weight, int blocksize,
+                        int quant_type, int w_dtype, const void *bias, int out_dtype, void *out,
+                        void *workspace, int64_t workspace_bytes, int flags, void *stream);
+
+/* The dense half of the large-M path on its own: out[M, N] = A[M, K] * W[N, ldw]^T (+ bias) for an f16 / bf16 weight that is
+ * already in the compute dtype (rows ldw >= K elements apart) -- the F.linear of functional.py:767 on the tensor
+ * functional.py:756 produced.  mbnb_matmul_4bit_ws calls it internally; exported for callers that keep a dequantised weight
+ * (e.g. Linear4bit.dequantize(), nn/linear4bit.py:204) and for tools/.  K % 64 == 0, K >= 128, ldw % 8 == 0, A and W 16-byte
+ * aligned; f32 accumulation, one rounding to `dtype`, then the cast to out_dtype.  slices > 1 splits K over
+ * slices * M * N * 4 bytes of workspace (partials added in slice order); slices == 1 needs no workspace. */
+int mbnb_gemm_dense(const void *A, const void *W, int dtype, const void *bias, int out_dtype, void *out,
+                    int64_t M, int64_t N, int64_t K, int64_t ldw, void *workspace, int64_t workspace_bytes,
+                    int slices, void *stream);
+
 /* ---------------------------------------------------------------------------
  * linear_int8 — replaces `_C.linear_int8` (mm:1836-1886, kernel mm:203-305) with the numerics
  * of Linear8bit.forward (nn/linear8bit.py:70-102):
@@ -194,8 +224,9 @@ int mbnb_matmul_int8(const int8_t *A, const int8_t *B, const float *A_scales,
 int mbnb_linear_int8(const void *X, int dtype, int64_t M, int64_t K, const int8_t *W,
                      const float *W_scales, int64_t N, const void *bias, void *out, void *stream);
 
-/* linear_int8 with a split-K workspace of mbnb_matmul_4bit_workspace_bytes(M, N, K) bytes (the policy is shared with
- * the 4-bit path; 0 = not needed).  workspace == NULL behaves exactly like mbnb_linear_int8. */
+/* linear_int8 with a split-K workspace of mbnb_linear_int8_workspace_bytes(M, N, K) bytes (0 = not needed).
+ * workspace == NULL behaves exactly like mbnb_linear_int8. */
+int64_t mbnb_linear_int8_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int mbnb_linear_int8_ws(const void *X, int dtype, int64_t M, int64_t K, const int8_t *W,
                         const float *W_scales, int64_t N, const void *bias, void *out, void *workspace,
                         int64_t workspace_bytes, void *stream);

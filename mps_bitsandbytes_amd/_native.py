@@ -54,8 +54,15 @@ _SIGNATURES = {
     "mbnb_matmul_4bit": (c_int, [c_void_p, c_int64, c_int64, c_void_p, POINTER(AbsmaxDesc), c_int64, c_int64,
                                  c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "mbnb_matmul_4bit_workspace_bytes": (c_int64, [c_int64, c_int64, c_int64]),
+    "mbnb_matmul_4bit_workspace_bytes_kw": (c_int64, [c_int64, c_int64, c_int64, c_int64]),
+    "mbnb_matmul_4bit_splitk_workspace_bytes": (c_int64, [c_int64, c_int64, c_int64]),
+    "mbnb_linear_int8_workspace_bytes": (c_int64, [c_int64, c_int64, c_int64]),
+    "mbnb_gemm_dense": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p,
+                        c_int64, c_int, c_void_p]),
     "mbnb_matmul_4bit_ws": (c_int, [c_void_p, c_int64, c_int64, c_void_p, POINTER(AbsmaxDesc), c_int64, c_int64,
                                     c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p]),
+    "mbnb_matmul_4bit_ex": (c_int, [c_void_p, c_int64, c_int64, c_void_p, POINTER(AbsmaxDesc), c_int64, c_int64,
+                                    c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "mbnb_matmul_int8_workspace_bytes": (c_int64, [c_int64, c_int64, c_int64]),
     "mbnb_matmul_int8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int,
                                  c_void_p, c_void_p, c_void_p]),

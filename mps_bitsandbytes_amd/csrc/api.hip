@@ -64,13 +64,17 @@ int dequant_absmax_dispatch(const void *, int, int64_t, int64_t, const float *, 
 int quantize_rowwise_dispatch(const void *, int, int64_t, int64_t, int8_t *, float *, hipStream_t);
 int dequantize_rowwise_dispatch(const int8_t *, const float *, int64_t, int64_t, int, void *, hipStream_t);
 int double_quant_dispatch(const void *, int, int64_t, int64_t, int8_t *, int8_t *, float *, float *, int, int, hipStream_t);
-int matmul_4bit_dispatch(const void *, int64_t, int64_t, const uint8_t *, const AbsmaxView &, int64_t, int64_t, int, int, int, const void *, int, void *, void *, int64_t, hipStream_t);
+int matmul_4bit_dispatch(const void *, int64_t, int64_t, const uint8_t *, const AbsmaxView &, int64_t, int64_t, int, int, int, const void *, int, void *, void *, int64_t, bool,
+                         hipStream_t);
 int quantize_fp8_dispatch(const void *, int, int64_t, int64_t, uint8_t *, float *, hipStream_t);
 int dequantize_fp8_dispatch(const uint8_t *, const float *, int64_t, int64_t, int, void *, hipStream_t);
 int linear_fp8_dispatch(const void *, int, int64_t, int64_t, const uint8_t *, const float *, int64_t, const void *, void *, void *, int64_t, hipStream_t);
 int64_t matmul4_splitk_slices(int64_t, int64_t, int64_t);
 int probe_mfma_dispatch(int, int, float *, hipStream_t);
 int64_t gemm_mid_workspace_bytes(int64_t, int64_t, int64_t);
+int64_t gemm_dense_workspace_bytes(int64_t, int64_t, int64_t, int64_t);
+int gemm_dense_direct(const void *, const void *, int, const void *, int, void *, int64_t, int64_t, int64_t, int64_t, float *, int64_t,
+                      hipStream_t);
 int matmul_int8_dispatch(const int8_t *, const int8_t *, const float *, const float *, int64_t, int64_t, int64_t, int, void *, void *, hipStream_t);
 int64_t matmul_int8_workspace_bytes(int64_t, int64_t, int64_t);
 int linear_int8_dispatch(const void *, int, int64_t, int64_t, const int8_t *, const float *, int64_t, const void *, void *, void *, int64_t, hipStream_t);
@@ -227,9 +231,10 @@ int mbnb_double_quant(const void *A, int dtype, int64_t rows, int64_t cols, int8
                                  static_cast<hipStream_t>(stream));
 }
 
-int mbnb_matmul_4bit_ws(const void *A, int64_t M, int64_t K, const uint8_t *packed, const mbnb_absmax *absmax, int64_t N,
+int mbnb_matmul_4bit_ex(const void *A, int64_t M, int64_t K, const uint8_t *packed, const mbnb_absmax *absmax, int64_t N,
                         int64_t K_weight, int blocksize, int quant_type, int w_dtype, const void *bias, int out_dtype,
-                        void *out, void *workspace, int64_t workspace_bytes, void *stream) {
+                        void *out, void *workspace, int64_t workspace_bytes, int flags, void *stream) {
+    if (flags & ~MBNB_MATMUL_FUSED_ONLY) return fail(MBNB_ERR_ARG, "matmul_4bit: unknown flags 0x%x", flags);
     if (!dtype_ok(w_dtype) || !dtype_ok(out_dtype) || !qt_ok(quant_type))
         return fail(MBNB_ERR_ARG, "matmul_4bit: bad dtype/quant_type");
     if (M < 0 || N < 0 || K < 0) return fail(MBNB_ERR_ARG, "matmul_4bit: negative size");
@@ -243,7 +248,15 @@ int mbnb_matmul_4bit_ws(const void *A, int64_t M, int64_t K, const uint8_t *pack
     if (!A || !packed || !out) return fail(MBNB_ERR_ARG, "matmul_4bit: NULL pointer");
     // the split-K workspace travels down the dispatch as an argument (no per-call state is kept anywhere)
     return matmul_4bit_dispatch(A, M, K, packed, v, N, K_weight, blocksize, quant_type, w_dtype, bias, out_dtype, out,
-                                workspace, workspace ? workspace_bytes : 0, static_cast<hipStream_t>(stream));
+                                workspace, workspace ? workspace_bytes : 0, (flags & MBNB_MATMUL_FUSED_ONLY) != 0,
+                                static_cast<hipStream_t>(stream));
+}
+
+int mbnb_matmul_4bit_ws(const void *A, int64_t M, int64_t K, const uint8_t *packed, const mbnb_absmax *absmax, int64_t N,
+                        int64_t K_weight, int blocksize, int quant_type, int w_dtype, const void *bias, int out_dtype,
+                        void *out, void *workspace, int64_t workspace_bytes, void *stream) {
+    return mbnb_matmul_4bit_ex(A, M, K, packed, absmax, N, K_weight, blocksize, quant_type, w_dtype, bias, out_dtype, out,
+                               workspace, workspace_bytes, 0, stream);
 }
 
 int mbnb_matmul_4bit(const void *A, int64_t M, int64_t K, const uint8_t *packed, const mbnb_absmax *absmax, int64_t N,
@@ -253,12 +266,44 @@ int mbnb_matmul_4bit(const void *A, int64_t M, int64_t K, const uint8_t *packed,
                                nullptr, 0, stream);
 }
 
-int64_t mbnb_matmul_4bit_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+int64_t mbnb_matmul_4bit_splitk_workspace_bytes(int64_t M, int64_t N, int64_t K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     const int64_t s = matmul4_splitk_slices(M, N, K);
     const int64_t a = s > 1 ? s * ((M + 127) / 128) * ((N + 127) / 128) * 65536 : 0;   // slices x tiles x 128 x 128 f32
     const int64_t b = gemm_mid_workspace_bytes(M, N, K);   // slices x M x N f32 (mid-sized batches, blocksize 64)
     return a > b ? a : b;
+}
+
+int64_t mbnb_matmul_4bit_workspace_bytes_kw(int64_t M, int64_t N, int64_t K, int64_t K_weight) {
+    if (M <= 0 || N <= 0 || K <= 0 || K_weight < K) return 0;
+    const int64_t ab = mbnb_matmul_4bit_splitk_workspace_bytes(M, N, K);
+    const int64_t c = gemm_dense_workspace_bytes(M, N, K, K_weight);   // the dequantised weight (+ split-K partials): large M
+    return ab > c ? ab : c;
+}
+
+int64_t mbnb_matmul_4bit_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+    return mbnb_matmul_4bit_workspace_bytes_kw(M, N, K, K);
+}
+
+int64_t mbnb_linear_int8_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const int64_t s = matmul4_splitk_slices(M, N, K);
+    return s > 1 ? s * ((M + 127) / 128) * ((N + 127) / 128) * 65536 : 0;   // slices x tiles x 128 x 128 f32
+}
+
+int mbnb_gemm_dense(const void *A, const void *W, int dtype, const void *bias, int out_dtype, void *out, int64_t M, int64_t N,
+                    int64_t K, int64_t ldw, void *workspace, int64_t workspace_bytes, int slices, void *stream) {
+    if ((dtype != MBNB_F16 && dtype != MBNB_BF16) || !dtype_ok(out_dtype)) return fail(MBNB_ERR_ARG, "gemm_dense: bad dtype");
+    if (M <= 0 || N <= 0 || K < 128 || K % 64 || ldw < K || ldw % 8) return fail(MBNB_ERR_SHAPE, "gemm_dense: bad shape");
+    if (256 * ldw * 2 >= ((int64_t)1 << 31)) return fail(MBNB_ERR_SHAPE, "gemm_dense: K too large");
+    if (!A || !W || !out) return fail(MBNB_ERR_ARG, "gemm_dense: NULL pointer");
+    if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(W) & 15))
+        return fail(MBNB_ERR_ARG, "gemm_dense: operands must be 16-byte aligned");
+    if (slices < 1 || slices > 16 || (int64_t)slices * 64 > K) return fail(MBNB_ERR_ARG, "gemm_dense: bad slice count");
+    if (slices > 1 && (!workspace || workspace_bytes < (int64_t)slices * M * N * 4 || (reinterpret_cast<uintptr_t>(workspace) & 15)))
+        return fail(MBNB_ERR_ARG, "gemm_dense: split-K needs slices * M * N * 4 bytes of 16-byte aligned workspace");
+    return gemm_dense_direct(A, W, dtype, bias, out_dtype, out, M, N, K, ldw, static_cast<float *>(workspace), slices,
+                             static_cast<hipStream_t>(stream));
 }
 
 int64_t mbnb_matmul_int8_workspace_bytes(int64_t M, int64_t N, int64_t K) {

@@ -1,0 +1,123 @@
+// gemm_dense.hip — "decode once" path of matmul_4bit for large M: dequantize_4bit writes the weight [N, K_weight] in the
+// compute dtype into the caller's workspace, k_gemm_dense (gemm_dense.h) multiplies.  Any blocksize / quant type / nested
+// absmax (the decode is dequantize_4bit's), f16 and bf16 compute.  Own translation unit (the kernel compiles for minutes).
+//
+// Workspace layout (mbnb_matmul_4bit_workspace_bytes reports the sum):
+//   [0, wd_bytes)                    Wd [N, K_weight] in the compute dtype, wd_bytes = N * K_weight * 2 rounded up to 256
+//   [wd_bytes, + slices * M * N * 4) f32 partials of the split-K slices (none when slices == 1)
+#include "gemm_dense.h"
+#include "gemm_mid.h"
+
+namespace mbnb {
+
+int dequantize_4bit_dispatch(const uint8_t *, const AbsmaxView &, int64_t, int64_t, int64_t, int, int, int, void *, hipStream_t);
+
+// The policy, from tools/exp/sweep_dense.py (profiles/r02_dense_sweep.txt).  The path is taken from 40 output tiles of
+// 256 x 256 and 512 rows up (below that the fused split-K kernels win: 512 x 4096 x 4096 runs 41 us fused, 49 us here).
+// Slices: the count that minimises   rounds(s) * k_steps(s) * 1.3 us  +  (s > 1) * 8 s M N bytes / 6 TB/s
+// -- workgroup rounds on 256 CUs times the measured k-step, plus the f32 partials written once and read once (what makes
+// split-K expensive here: two slices of a 4096 x 4096 output move 256 MB, 36 us measured).  The model reproduces the
+// measured best slice count on every shape of the sweep.
+int64_t gemm_dense_slices(int64_t M, int64_t N, int64_t K) {
+    const int64_t tiles = ((M + 255) / 256) * ((N + 255) / 256);
+    // From 96 tiles up never split, although two slices measure up to 13 % faster at 96-128 tiles: an unsplit product has the
+    // same bits for a row whatever M it is computed in, which is what lets row shards and row chunks of a large batch
+    // (sharding.py, bench.py --gpus N --verify) be compared bit for bit with the unsharded result.
+    if (tiles >= 96) return 1;
+    const int64_t steps = K / 64;
+    int64_t best = 1;
+    double best_t = 1e30;
+    for (int64_t s = 1; s <= 8; s++) {
+        const int64_t per = (steps + s - 1) / s;
+        if (s > 1 && per < 8) break;
+        const int64_t rounds = (tiles * s + 255) / 256;
+        const double t = (double)rounds * (double)per * 1.3 + (s > 1 ? 8.0 * (double)s * (double)M * (double)N / 6.0e6 : 0.0);
+        if (t < best_t) {
+            best_t = t;
+            best = s;
+        }
+    }
+    return best;
+}
+int64_t gemm_dense_k_per_slice(int64_t K, int64_t slices) {
+    const int64_t steps = K / 64;
+    return ((steps + slices - 1) / slices) * 64;
+}
+bool gemm_dense_shape(int64_t M, int64_t N, int64_t K, int64_t K_weight) {
+    if (K % 64 != 0 || K < 128 || K_weight % 8 != 0) return false;
+    if (256 * (K > K_weight ? K : K_weight) * 2 >= ((int64_t)1 << 31)) return false;
+    if (M * N * 4 >= ((int64_t)1 << 40)) return false;
+    return M >= 512 && ((M + 255) / 256) * ((N + 255) / 256) >= 40;
+}
+int64_t gemm_dense_wd_bytes(int64_t N, int64_t K_weight) { return (N * K_weight * 2 + 255) & ~(int64_t)255; }
+int64_t gemm_dense_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t K_weight) {
+    if (!gemm_dense_shape(M, N, K, K_weight)) return 0;
+    const int64_t s = gemm_dense_slices(M, N, K);
+    return gemm_dense_wd_bytes(N, K_weight) + (s > 1 ? s * M * N * 4 : 0);
+}
+
+template <typename T>
+static int launch_gemm_dense(const T *x, const T *wd, const T *bias, void *out, int out_dtype, int64_t M, int64_t N, int64_t K,
+                             int64_t ldw, float *partial, int64_t slices, hipStream_t st) {
+    const int64_t tiles = ((M + 255) / 256) * ((N + 255) / 256);
+    if (slices <= 1) {
+        auto kern = k_gemm_dense<T, false>;
+        if (int rc = ensure_dyn_lds(reinterpret_cast<const void *>(kern), GD_LDS, "matmul_4bit(dense)")) return rc;
+        hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), GD_LDS, st, x, wd, bias, out, out_dtype, static_cast<float *>(nullptr),
+                           M, N, K, ldw, K);
+        return check_launch("matmul_4bit(dense)");
+    }
+    auto kern = k_gemm_dense<T, true>;
+    if (int rc = ensure_dyn_lds(reinterpret_cast<const void *>(kern), GD_LDS, "matmul_4bit(dense split-K)")) return rc;
+    const int64_t kps = gemm_dense_k_per_slice(K, slices);
+    const int64_t used = (K + kps - 1) / kps;    // no empty slice
+    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * used)), dim3(256), GD_LDS, st, x, wd, bias, out, out_dtype, partial, M, N, K, ldw,
+                       kps);
+    if (int rc = check_launch("matmul_4bit(dense split-K)")) return rc;
+    const int64_t groups = M * ((N + 3) / 4);
+    const unsigned blocks = (unsigned)((groups + 255) / 256);
+    if (out_dtype == MBNB_F32)
+        hipLaunchKernelGGL((k_splitk_reduce_rm<T, float>), dim3(blocks), dim3(256), 0, st, partial, (int)used, bias, static_cast<float *>(out), M, N);
+    else if (out_dtype == MBNB_F16)
+        hipLaunchKernelGGL((k_splitk_reduce_rm<T, f16_t>), dim3(blocks), dim3(256), 0, st, partial, (int)used, bias, static_cast<f16_t *>(out), M, N);
+    else
+        hipLaunchKernelGGL((k_splitk_reduce_rm<T, bf16_t>), dim3(blocks), dim3(256), 0, st, partial, (int)used, bias, static_cast<bf16_t *>(out), M, N);
+    return check_launch("matmul_4bit(dense split-K reduce)");
+}
+
+// Returns 1 when the path does not apply (caller falls through to the fused kernels), otherwise the launch status.
+int matmul_4bit_dense_path(const void *A, int64_t M, int64_t K, const uint8_t *packed, const AbsmaxView &am, int64_t N,
+                           int64_t K_weight, int blocksize, int qt, int w_dtype, const void *bias, int out_dtype, void *out,
+                           void *ws, int64_t ws_bytes, hipStream_t st) {
+    if (w_dtype != MBNB_F16 && w_dtype != MBNB_BF16) return 1;
+    if (!gemm_dense_shape(M, N, K, K_weight) || ws == nullptr) return 1;
+    if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(ws) & 255) || (reinterpret_cast<uintptr_t>(packed) & 3)) return 1;
+    const int64_t wd_bytes = gemm_dense_wd_bytes(N, K_weight);
+    if (ws_bytes < wd_bytes) return 1;
+    int64_t slices = gemm_dense_slices(M, N, K);
+    if (slices > 1 && ws_bytes < wd_bytes + slices * M * N * 4) slices = 1;   // a short workspace costs the split, not the path
+    char *wsb = static_cast<char *>(ws);
+    if (int rc = dequantize_4bit_dispatch(packed, am, N, K_weight, K_weight, blocksize, qt, w_dtype, wsb, st)) return rc;
+    float *partial = reinterpret_cast<float *>(wsb + wd_bytes);
+    int rc;
+    if (w_dtype == MBNB_F16)
+        rc = launch_gemm_dense<f16_t>(static_cast<const f16_t *>(A), reinterpret_cast<const f16_t *>(wsb), static_cast<const f16_t *>(bias),
+                                      out, out_dtype, M, N, K, K_weight, partial, slices, st);
+    else
+        rc = launch_gemm_dense<bf16_t>(static_cast<const bf16_t *>(A), reinterpret_cast<const bf16_t *>(wsb),
+                                       static_cast<const bf16_t *>(bias), out, out_dtype, M, N, K, K_weight, partial, slices, st);
+    set_kernel_name(slices > 1 ? "dequant+dense_splitk" : "dequant+dense");
+    return rc;
+}
+
+// diagnostic entry for tools/exp (the dense kernel alone on a caller-made Wd)
+int gemm_dense_direct(const void *A, const void *Wd, int dtype, const void *bias, int out_dtype, void *out, int64_t M, int64_t N,
+                      int64_t K, int64_t ldw, float *partial, int64_t slices, hipStream_t st) {
+    if (dtype == MBNB_F16)
+        return launch_gemm_dense<f16_t>(static_cast<const f16_t *>(A), static_cast<const f16_t *>(Wd), static_cast<const f16_t *>(bias), out,
+                                        out_dtype, M, N, K, ldw, partial, slices, st);
+    return launch_gemm_dense<bf16_t>(static_cast<const bf16_t *>(A), static_cast<const bf16_t *>(Wd), static_cast<const bf16_t *>(bias), out,
+                                     out_dtype, M, N, K, ldw, partial, slices, st);
+}
+
+}  // namespace mbnb

@@ -30,6 +30,8 @@ template <typename T, typename OutT, bool NESTED, int ABL = 0>
 int launch_gemm_mid(const T *x, const typename Q4ProducerRT<T, NESTED>::Params &wp, const T *bias, OutT *out, int64_t M,
                     int64_t N, int64_t K, float *ws, int64_t ws_bytes, int force_slices, hipStream_t st);
 bool gemm_mid_shape(int64_t M, int64_t N, int64_t K);
+int matmul_4bit_dense_path(const void *, int64_t, int64_t, const uint8_t *, const AbsmaxView &, int64_t, int64_t, int, int, int, const void *,
+                           int, void *, void *, int64_t, hipStream_t);
 
 // =====================================================================================
 // generic kernel: wave per (n, m-chunk of MT rows); lanes stride over k in steps of 8
@@ -449,7 +451,13 @@ extern "C" int mbnb_debug_read_stamps(unsigned long long *host_out) {
 
 int matmul_4bit_dispatch(const void *A, int64_t M, int64_t K, const uint8_t *packed, const AbsmaxView &am, int64_t N,
                          int64_t K_weight, int blocksize, int qt, int w_dtype, const void *bias, int out_dtype,
-                         void *out, void *workspace, int64_t ws_bytes, hipStream_t st) {
+                         void *out, void *workspace, int64_t ws_bytes, bool fused_only, hipStream_t st) {
+    // large M: decode the weight once into the workspace, then the dense MFMA GEMM (gemm_dense.hip); 1 = does not apply
+    if (!fused_only) {
+        const int rc = matmul_4bit_dense_path(A, M, K, packed, am, N, K_weight, blocksize, qt, w_dtype, bias, out_dtype, out, workspace,
+                                              ws_bytes, st);
+        if (rc != 1) return rc;
+    }
     float *ws = static_cast<float *>(workspace);
     switch (w_dtype) {
         case MBNB_F16: return matmul4_out<f16_t>(A, M, K, packed, am, N, K_weight, blocksize, qt, bias, out_dtype, out, ws, ws_bytes, st);

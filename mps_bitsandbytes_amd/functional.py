@@ -62,6 +62,12 @@ def _check_device(tensor: Tensor, operation: str = "operation"):
 _warned: set = set()
 
 
+# matmul_4bit at >= 512 rows: let the library dequantise the weight ONCE into a transient N x K scratch (in the weight dtype)
+# and run a dense MFMA GEMM -- what the reference does for M > 512 (functional.py:753-767) -- instead of the fused kernels,
+# which decode each weight tile once per 256 rows.  False keeps the fused kernels at every M (no N x K scratch).
+DECODE_ONCE = True
+
+
 def _warn_once(key: str, message: str) -> None:
     if key not in _warned:
         _warned.add(key)
@@ -547,15 +553,20 @@ def matmul_4bit(
     out = torch.empty(M, N, dtype=out_dtype, device=A.device)
     keep: list = []
     desc = _absmax_desc(quant_state.absmax.to(A.device), quant_state.state2, keep)
-    # mid-sized M leaves too few output tiles for 256 CUs: the library then splits K over a caller-provided f32
-    # workspace (0 bytes = not needed for this shape); torch's caching allocator makes the allocation a pointer bump
-    ws_bytes = int(_native.lib().mbnb_matmul_4bit_workspace_bytes(M, N, K))
+    # The library's scratch (0 bytes = none needed for this shape): mid-sized M leaves too few output tiles for 256 CUs and
+    # K is split over f32 partials; large M (>= 512) decodes the weight ONCE into it (N x K_weight in the weight dtype) and
+    # runs a dense MFMA GEMM instead of re-decoding every weight tile per 256 rows.  torch's caching allocator makes the
+    # allocation a pointer bump; the memory goes back to the pool on return.
+    if DECODE_ONCE:
+        ws_bytes = int(_native.lib().mbnb_matmul_4bit_workspace_bytes_kw(M, N, K, K_weight))
+    else:
+        ws_bytes = int(_native.lib().mbnb_matmul_4bit_splitk_workspace_bytes(M, N, K))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=A.device) if ws_bytes > 0 else None
     with torch.cuda.device(A.device):
-        check(_native.lib().mbnb_matmul_4bit_ws(
+        check(_native.lib().mbnb_matmul_4bit_ex(
             ptr(A2), M, K, ptr(packed), ctypes.byref(desc), N, K_weight, int(blocksize),
             _native.QUANT_CODE[quant_state.quant_type], w_code, ptr(bias_w), _native.DTYPE_CODE[out_dtype],
-            ptr(out), ptr(ws), ws_bytes, stream_ptr(A.device)), "matmul_4bit")
+            ptr(out), ptr(ws), ws_bytes, 0 if DECODE_ONCE else 1, stream_ptr(A.device)), "matmul_4bit")
     if out_dtype != compute_dtype:
         out = out.to(compute_dtype)
     return out.reshape(*orig_shape[:-1], N)
@@ -629,7 +640,7 @@ def linear_int8(input: Tensor, weight_int8: Tensor, weight_scales: Tensor, bias:
     s = weight_scales.to(device=x.device, dtype=torch.float32).contiguous()
     b = None if bias is None else bias.to(device=x.device, dtype=dtype).contiguous()
     out = torch.empty(M, N, dtype=dtype, device=x.device)
-    ws_bytes = int(_native.lib().mbnb_matmul_4bit_workspace_bytes(M, N, K)) if M > 64 else 0   # split-K for mid-sized M
+    ws_bytes = int(_native.lib().mbnb_linear_int8_workspace_bytes(M, N, K)) if M > 64 else 0   # split-K for mid-sized M
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes > 0 else None
     with torch.cuda.device(x.device):
         check(_native.lib().mbnb_linear_int8_ws(ptr(x), dcode, M, K, ptr(w), ptr(s), N, ptr(b), ptr(out), ptr(ws), ws_bytes,
@@ -692,7 +703,7 @@ def matmul_fp8_e4m3(input: Tensor, weight: Tensor, weight_scales: Tensor, bias: 
     s = weight_scales.to(device=x2.device, dtype=torch.float32).contiguous()
     b = None if bias is None else bias.to(device=x2.device, dtype=dtype).contiguous()
     out = torch.empty(M, N, dtype=dtype, device=x2.device)
-    ws_bytes = int(_native.lib().mbnb_matmul_4bit_workspace_bytes(M, N, K)) if M > 64 else 0
+    ws_bytes = int(_native.lib().mbnb_linear_int8_workspace_bytes(M, N, K)) if M > 64 else 0
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x2.device) if ws_bytes > 0 else None
     with torch.cuda.device(x2.device):
         check(_native.lib().mbnb_linear_fp8(ptr(x2), dcode, M, K, ptr(w), ptr(s), N, ptr(b), ptr(out), ptr(ws), ws_bytes,

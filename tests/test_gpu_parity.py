@@ -224,11 +224,47 @@ def test_matmul_mfma_path(shape, dt):
     dict(M=3000, N=2304, K=384, dt=torch.float16, cs=True, bs=128, cd=torch.float32),
     dict(M=2304, N=3000, K=64, dt=torch.float16, cd=torch.bfloat16),      # single k-step
 ])
-def test_matmul_mfma256_path(case):
-    """The 256x256 one-workgroup-per-CU kernel (dispatched for >= 96 tiles)."""
+def test_matmul_mfma256_path(case, monkeypatch):
+    """The fused 256x256 one-workgroup-per-CU kernel (dispatched for >= 96 tiles when the caller gives no N x K scratch)."""
+    monkeypatch.setattr(bnb.functional, "DECODE_ONCE", False)
     c = dict(case)
     kern = _oracle_vs_gpu_matmul(c.pop("M"), c.pop("N"), c.pop("K"), c.pop("dt"), seed=25, **c)
     assert kern == "mfma256"
+
+
+@pytest.mark.parametrize("case", [
+    dict(M=2560, N=2560, K=256, dt=torch.bfloat16),
+    dict(M=2500, N=2600, K=192, dt=torch.float16),                       # ragged M and N edges: rows past M / N read as zeros
+    dict(M=2500, N=2600, K=128, dt=torch.bfloat16, qt="fp4", cs=True, bs=32),
+    dict(M=3000, N=2304, K=384, dt=torch.float16, cs=True, bs=128, cd=torch.float32),
+    dict(M=2304, N=3000, K=192, dt=torch.float16, bs=128, cd=torch.bfloat16),   # K_weight = 256 > K: weight pitch != K
+    dict(M=515, N=5000, K=640, dt=torch.bfloat16, bs=4096),              # one absmax block spans several rows' worth of k
+    dict(M=1024, N=4096, K=1024, dt=torch.bfloat16, cs=True),            # split-K over f32 partials
+    dict(M=768, N=4000, K=2048, dt=torch.float16, qt="fp4"),             # split-K, ragged N
+    dict(M=700, N=3800, K=1088, dt=torch.bfloat16, cd=torch.float32),    # split-K with a short last slice, f32 output
+])
+def test_matmul_decode_once_path(case, monkeypatch):
+    """Large M through the Python API: dequantize_4bit into the scratch + k_gemm_dense (gemm_dense.h), any blocksize / code
+    table / nested absmax.  Parity vs the oracle, and -- same B-operand bits, same f32 chain per output -- the unsplit path
+    equals the fused 256 x 256 kernel bit for bit."""
+    c = dict(case)
+    M, N, K, dt = c.pop("M"), c.pop("N"), c.pop("K"), c.pop("dt")
+    kern = _oracle_vs_gpu_matmul(M, N, K, dt, seed=25, **c)
+    assert kern in ("dequant+dense", "dequant+dense_splitk"), kern
+    W = synthetic.normal((N, K), dt, seed=25)
+    X = synthetic.normal((M, K), dt, seed=26).to(DEV)
+    b = synthetic.normal((N,), dt, seed=27).to(DEV)
+    packed, st = bnb.quantize_4bit(W.to(DEV), blocksize=c.get("bs", 64), quant_type=c.get("qt", "nf4"), compress_statistics=c.get("cs", False))
+    y = bnb.matmul_4bit(X, packed, st, b, c.get("cd"))
+    assert _native.last_kernel() == kern
+    assert torch.equal(y, bnb.matmul_4bit(X, packed, st, b, c.get("cd"))), "decode-once path is not run-to-run deterministic"
+    monkeypatch.setattr(bnb.functional, "DECODE_ONCE", False)
+    y_fused = bnb.matmul_4bit(X, packed, st, b, c.get("cd"))
+    assert "dense" not in _native.last_kernel()
+    if kern == "dequant+dense" and _native.last_kernel() == "mfma256":
+        assert torch.equal(y, y_fused), "dense and fused 256 x 256 kernels disagree"
+    else:
+        assert rel_fro(y, y_fused.cpu()) <= TOL[dt]
 
 
 @pytest.mark.parametrize("qt", ["nf4", "fp4"])
@@ -302,7 +338,7 @@ def test_matmul_row_independence_and_linearity_full_size():
     assert torch.equal(packed.cpu(), o_packed)
     X = synthetic.normal((M, K), torch.float16, seed=4321).to(DEV)
     Y = bnb.matmul_4bit(X, packed, st)
-    assert "mfma" in _native.last_kernel()
+    assert _native.last_kernel() == "dequant+dense"
     assert torch.isfinite(Y).all()
     rows = torch.tensor(sorted(set(list(range(16)) + [int(v) for v in synthetic.uniform_u64(32, 9) % np.uint64(M)])))
     y_ref = oracle.matmul_4bit(X[rows.to(DEV)].cpu(), o_packed, o_absmax, (N, K), 64, "nf4", torch.float16)
@@ -621,8 +657,16 @@ def test_matmul_benched_instantiation_bf16_plain_full_size():
     assert torch.equal(packed.cpu(), op) and torch.equal(st.absmax.cpu(), oa)
     X = synthetic.normal((M, K), torch.bfloat16, seed=4321).to(DEV)
     Y = bnb.matmul_4bit(X, packed, st)
-    assert _native.last_kernel() == "mfma256"
+    assert _native.last_kernel() == "dequant+dense"
     assert Y.dtype == torch.bfloat16 and torch.isfinite(Y).all()
+    # the fused kernel (what a caller without the N x K scratch gets) computes the same bits
+    bnb.functional.DECODE_ONCE = False
+    try:
+        Yf = bnb.matmul_4bit(X, packed, st)
+        assert _native.last_kernel() == "mfma256"
+    finally:
+        bnb.functional.DECODE_ONCE = True
+    assert torch.equal(Y, Yf), "k_gemm_dense and k_gemm256s disagree at 4096^3"
     rows = sorted(set([t * 256 + (37 * t + 5) % 256 for t in range(16)] + list(range(8)) + [M - 1, M - 2, M - 33] +
                       [int(v) for v in synthetic.uniform_u64(24, 19) % np.uint64(M)]))
     rows_t = torch.tensor(rows)
@@ -632,7 +676,7 @@ def test_matmul_benched_instantiation_bf16_plain_full_size():
     # element-wise as well: no single output may be off by more than a few bf16 ulps of the row scale
     diff = (Y[rows_t.to(DEV)].float().cpu() - y_ref.float()).abs().max().item()
     assert diff <= 4e-2 * y_ref.float().abs().max().item()
-    assert torch.equal(Y, bnb.matmul_4bit(X, packed, st)), "mfma256 is not run-to-run deterministic"
+    assert torch.equal(Y, bnb.matmul_4bit(X, packed, st)), "the benched path is not run-to-run deterministic"
     # bias through the LDS-staged epilogue of the same instantiation
     bias = synthetic.normal((N,), torch.bfloat16, seed=77)
     Yb = bnb.matmul_4bit(X, packed, st, bias.to(DEV))
@@ -654,7 +698,7 @@ def test_matmul_config4_global_shape_on_one_gpu():
     g.manual_seed(99)
     X = torch.randn(M, K, generator=g, device=DEV, dtype=torch.float32).to(torch.bfloat16)
     Y = bnb.matmul_4bit(X, packed, st)
-    assert _native.last_kernel() == "mfma256" and Y.shape == (M, N)
+    assert _native.last_kernel() == "dequant+dense" and Y.shape == (M, N)
     assert torch.isfinite(Y).all()
     rows = sorted(set([t * 2048 + (611 * t + 3) % 2048 for t in range(16)] + [0, 1, 255, 256, M - 257, M - 256, M - 1] +
                       [int(v) for v in synthetic.uniform_u64(16, 23) % np.uint64(M)]))
@@ -708,7 +752,7 @@ def test_bench_gpus_flag_spawns_ranks_and_gathers_the_unsharded_result():
     line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
     rec = json.loads(line)
     assert rec["n_gpus"] == 2 and rec["verified"] is True
-    assert rec["config"]["global_rows"] == 8192 and rec["config"]["kernel"] == "mfma256"
+    assert rec["config"]["global_rows"] == 8192 and rec["config"]["kernel"] == "dequant+dense"
     for curve in ("gemm_only", "sync", "overlapped", "chunked"):
         assert rec[curve]["value"] > 0
 

@@ -55,16 +55,31 @@ def test_argument_errors_use_status_and_last_error():
 
 
 def test_workspace_size_functions_are_pure_host_code():
-    """Split-K policy (mbnb_matmul_4bit_workspace_bytes): no workspace for GEMV / skinny-sized M or for shapes that
-    fill the chip with 256 x 256 tiles; slices x tiles x 64 KiB (128 x 128 f32) in between."""
+    """Workspace policy.  Split-K share: nothing for GEMV / skinny-sized M or for shapes that fill the chip with 256 x 256
+    tiles; slices x tiles x 64 KiB (128 x 128 f32) in between.  Full query: from 512 rows and 40 tiles of 256 x 256 up the
+    dequantised weight (N x K_weight x 2 bytes, 256-byte granules) plus slices x M x N f32 partials."""
     lib = _native.lib()
-    assert lib.mbnb_matmul_4bit_workspace_bytes(1, 4096, 4096) == 0
-    assert lib.mbnb_matmul_4bit_workspace_bytes(4, 4096, 4096) == 0
-    assert lib.mbnb_matmul_4bit_workspace_bytes(4096, 4096, 4096) == 0           # 256 tiles of 256^2
-    assert lib.mbnb_matmul_4bit_workspace_bytes(128, 4096, 4096) == 16 * 32 * 65536   # 32 tiles -> 16 slices of 256 k
-    assert lib.mbnb_matmul_4bit_workspace_bytes(1024, 4096, 4096) == 2 * 256 * 65536
-    assert lib.mbnb_matmul_4bit_workspace_bytes(128, 4096, 72) == 0               # K % 64 != 0
-    assert lib.mbnb_matmul_4bit_workspace_bytes(0, 4096, 4096) == 0
+    sk = lib.mbnb_matmul_4bit_splitk_workspace_bytes
+    assert sk(1, 4096, 4096) == 0
+    assert sk(4, 4096, 4096) == 0
+    assert sk(4096, 4096, 4096) == 0                        # 256 tiles of 256^2
+    assert sk(128, 4096, 4096) == 16 * 32 * 65536           # 32 tiles -> 16 slices of 256 k
+    assert sk(1024, 4096, 4096) == 2 * 256 * 65536
+    assert sk(128, 4096, 72) == 0                           # K % 64 != 0
+    assert sk(0, 4096, 4096) == 0
+    assert lib.mbnb_linear_int8_workspace_bytes(1024, 4096, 4096) == 2 * 256 * 65536
+    full = lib.mbnb_matmul_4bit_workspace_bytes
+    assert full(128, 4096, 4096) == sk(128, 4096, 4096)     # below 512 rows: the split-K share only
+    assert full(512, 4096, 4096) == sk(512, 4096, 4096)     # 32 tiles of 256^2: not yet
+    assert full(4096, 4096, 4096) == 4096 * 4096 * 2        # the dequantised weight, no split (256 tiles)
+    assert full(32768, 4096, 4096) == 4096 * 4096 * 2
+    assert full(1024, 4096, 4096) == 4096 * 4096 * 2 + 4 * 1024 * 4096 * 4   # 64 tiles -> 4 slices of f32 partials
+    assert full(2048, 4096, 4096) == 4096 * 4096 * 2        # from 96 tiles up: never split (row bits independent of M)
+    assert full(4096, 4096, 4104) == sk(4096, 4096, 4104)   # K % 64 != 0: fused kernels only
+    kw = lib.mbnb_matmul_4bit_workspace_bytes_kw
+    assert kw(4096, 4096, 4096, 4096) == full(4096, 4096, 4096)
+    assert kw(4096, 1000, 192, 256) == ((1000 * 256 * 2 + 255) // 256) * 256   # padded weight rows
+    assert kw(4096, 4096, 4096, 4095) == 0                  # K_weight < K: not a weight
     assert lib.mbnb_outlier_linear_workspace_bytes(4096, 4096) == 4096 * 4096 + 4 * 4096 + 32 * 4096
     assert lib.mbnb_outlier_linear_workspace_bytes(3, 5) == 256 + 256 + 256
 

@@ -57,7 +57,7 @@ for name in ("fetch", "write", "tcc", "sq", "lds"):
         continue
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(files[0])):
-        if "k_gemm256s" in r["Kernel_Name"] or "k_gemm256p" in r["Kernel_Name"]:
+        if "k_gemm_dense" in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
             if name == "sq" and r["Counter_Name"] == "SQ_WAVE_CYCLES":
                 dur.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
@@ -66,22 +66,22 @@ for name in ("fetch", "write", "tcc", "sq", "lds"):
 if "FETCH_SIZE" in res:
     fetch, write = res["FETCH_SIZE"]["mean"], res["WRITE_SIZE"]["mean"]
     out = {
-        "kernel": "k_gemm256s<bf16, plain absmax, RAW2> (mfma256), M=N=K=4096, NF4 bs64",
+        "kernel": "k_gemm_dense<bf16> (dequant+dense), M=N=K=4096, weight dequantised once from NF4 bs64",
         "source": "rocprofv3 --kernel-trace --pmc <set> -- python3 bench.py --no-cpu-baseline --no-gemv --steps 5 --warmup 3; "
                   "separate passes: FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum | SQ_* | SQ_LDS_*",
         "gfx950_correction": "FETCH_SIZE counts 64 B per 128-B request on wide coalesced reads: doubled (MI355X_MICROARCH.md, HBM)",
         "FETCH_SIZE_KB_raw": fetch, "WRITE_SIZE_KB": write,
         "fetch_bytes_per_launch": int(2 * fetch * 1024), "write_bytes_per_launch": int(write * 1024),
-        "k_gemm256p_bytes_per_launch": int((2 * fetch + write) * 1024),
-        "algorithmic_bytes_per_launch": 76546048,
+        "k_gemm_dense_bytes_per_launch": int((2 * fetch + write) * 1024),
+        "algorithmic_bytes_per_launch": 3 * 4096 * 4096 * 2,
         "l2_hit_rate": res["TCC_HIT_sum"]["mean"] / (res["TCC_HIT_sum"]["mean"] + res["TCC_MISS_sum"]["mean"]),
     }
     if dur and "SQ_WAVE_CYCLES" in res:
         d = sum(dur) / len(dur)
         wc = res["SQ_WAVE_CYCLES"]["mean"]
         out["profiled_duration_us"] = d / 1e3
-        out["effective_clock_ghz"] = wc * 4 / 2048 / d          # SQ_WAVE_CYCLES counts quad-cycles summed over 2048 waves
-        out["mfma_pipe_utilisation"] = res["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] / 1024 / (wc * 4 / 2048)
+        out["effective_clock_ghz"] = wc * 4 / 1024 / d          # SQ_WAVE_CYCLES counts quad-cycles summed over 1024 waves
+        out["mfma_pipe_utilisation"] = res["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] / 1024 / (wc * 4 / 1024)
         for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS"):
             if k in res:
                 out[k + "_per_wave_cycle"] = res[k]["mean"] / wc
