@@ -154,7 +154,7 @@ def bench_nn(args, wl, dev, bnb, synthetic):
         name = "Linear8bit (row-wise INT8 weights)" if wl == "w8a16" else "LinearFP8 (E4M3 weights, reference format)"
         out.update({"metric": f"effective bf16 TFLOPS, {name} forward 4096x4096 @ M=4096", "value": round(flops / (elapsed / args.steps) / 1e12, 1),
                     "unit": "TFLOP/s", "ms_per_step": round(elapsed / args.steps * 1e3, 5), "dtype": "bf16",
-                    "config": {"workload": f"{name}.forward, bf16 activations, weights decoded inside the 256 x 256 LDS-DMA GEMM", "M": M, "N": N, "K": K,
+                    "config": {"workload": f"{name}.forward, bf16 activations, weights dequantised once into the workspace + k_gemm_dense at this M (fused W8A16 kernels below 512 rows)", "M": M, "N": N, "K": K,
                                "kernel": __import__("mps_bitsandbytes_amd")._native.last_kernel()},
                     "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s",
                                  "frac": round(tf / PEAK_TFLOPS["bf16"], 4), "traffic": None, "kernel_us": round(kern_ms * 1e3, 2)}})

@@ -224,8 +224,11 @@ int mbnb_gemm_dense(const void *A, const void *W, int dtype, const void *bias, i
 int mbnb_linear_int8(const void *X, int dtype, int64_t M, int64_t K, const int8_t *W,
                      const float *W_scales, int64_t N, const void *bias, void *out, void *stream);
 
-/* linear_int8 with a split-K workspace of mbnb_linear_int8_workspace_bytes(M, N, K) bytes (0 = not needed).
- * workspace == NULL behaves exactly like mbnb_linear_int8. */
+/* linear_int8 with a workspace of mbnb_linear_int8_workspace_bytes(M, N, K) bytes (0 = not needed; 256-byte aligned):
+ * split-K partials for mid-sized M; from 512 rows and 40 output tiles of 256 x 256 up the weight dequantised ONCE
+ * (dequantize_rowwise's bits, [N, K] in `dtype`) followed by the dense MFMA GEMM of csrc/gemm_dense.h -- the reference's own
+ * two steps (nn/linear8bit.py:70-102).  workspace == NULL behaves exactly like mbnb_linear_int8.  mbnb_linear_fp8 takes the
+ * same workspace. */
 int64_t mbnb_linear_int8_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int mbnb_linear_int8_ws(const void *X, int dtype, int64_t M, int64_t K, const int8_t *W,
                         const float *W_scales, int64_t N, const void *bias, void *out, void *workspace,

@@ -110,6 +110,38 @@ int matmul_4bit_dense_path(const void *A, int64_t M, int64_t K, const uint8_t *p
     return rc;
 }
 
+int dequantize_rowwise_dispatch(const int8_t *, const float *, int64_t, int64_t, int, void *, hipStream_t);
+int dequantize_fp8_dispatch(const uint8_t *, const float *, int64_t, int64_t, int, void *, hipStream_t);
+
+// Linear8bit.forward / LinearFP8.forward at large M (nn/linear8bit.py:70-102, functional.py:796-807): the reference's own two
+// steps -- dequantize_rowwise / dequantize_fp8_e4m3 into the compute dtype, then F.linear -- on the workspace.  Same policy
+// and workspace layout as the 4-bit path.  Returns 1 when it does not apply.
+int linear8_dense_path(const void *X, int dtype, int64_t M, int64_t K, const void *W, const float *scales, int64_t N, bool fp8,
+                       const void *bias, void *out, void *ws, int64_t ws_bytes, hipStream_t st) {
+    if (dtype != MBNB_F16 && dtype != MBNB_BF16) return 1;
+    if (!gemm_dense_shape(M, N, K, K) || ws == nullptr) return 1;
+    if ((reinterpret_cast<uintptr_t>(X) & 15) || (reinterpret_cast<uintptr_t>(ws) & 255)) return 1;
+    const int64_t wd_bytes = gemm_dense_wd_bytes(N, K);
+    if (ws_bytes < wd_bytes) return 1;
+    int64_t slices = gemm_dense_slices(M, N, K);
+    if (slices > 1 && ws_bytes < wd_bytes + slices * M * N * 4) slices = 1;
+    char *wsb = static_cast<char *>(ws);
+    const int rcq = fp8 ? dequantize_fp8_dispatch(static_cast<const uint8_t *>(W), scales, N, K, dtype, wsb, st)
+                        : dequantize_rowwise_dispatch(static_cast<const int8_t *>(W), scales, N, K, dtype, wsb, st);
+    if (rcq) return rcq;
+    float *partial = reinterpret_cast<float *>(wsb + wd_bytes);
+    int rc;
+    if (dtype == MBNB_F16)
+        rc = launch_gemm_dense<f16_t>(static_cast<const f16_t *>(X), reinterpret_cast<const f16_t *>(wsb), static_cast<const f16_t *>(bias),
+                                      out, dtype, M, N, K, K, partial, slices, st);
+    else
+        rc = launch_gemm_dense<bf16_t>(static_cast<const bf16_t *>(X), reinterpret_cast<const bf16_t *>(wsb),
+                                       static_cast<const bf16_t *>(bias), out, dtype, M, N, K, K, partial, slices, st);
+    set_kernel_name(fp8 ? (slices > 1 ? "fp8a16_dequant+dense_splitk" : "fp8a16_dequant+dense")
+                        : (slices > 1 ? "w8a16_dequant+dense_splitk" : "w8a16_dequant+dense"));
+    return rc;
+}
+
 // diagnostic entry for tools/exp (the dense kernel alone on a caller-made Wd)
 int gemm_dense_direct(const void *A, const void *Wd, int dtype, const void *bias, int out_dtype, void *out, int64_t M, int64_t N,
                       int64_t K, int64_t ldw, float *partial, int64_t slices, hipStream_t st) {

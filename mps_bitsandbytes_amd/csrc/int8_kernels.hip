@@ -737,8 +737,15 @@ static int launch_linear_int8(const void *X, int64_t M, int64_t K, const int8_t 
     return check_launch("linear_int8(generic)");
 }
 
+int linear8_dense_path(const void *, int, int64_t, int64_t, const void *, const float *, int64_t, bool, const void *, void *, void *, int64_t,
+                       hipStream_t);
+
 int linear_int8_dispatch(const void *X, int dtype, int64_t M, int64_t K, const int8_t *W, const float *scales,
                          int64_t N, const void *bias, void *out, void *workspace, int64_t ws_bytes, hipStream_t st) {
+    {   // large M: dequantise once into the workspace + dense GEMM (gemm_dense.hip); 1 = does not apply
+        const int rc = linear8_dense_path(X, dtype, M, K, W, scales, N, false, bias, out, workspace, ws_bytes, st);
+        if (rc != 1) return rc;
+    }
     float *ws = static_cast<float *>(workspace);
     switch (dtype) {
         case MBNB_F16: return launch_linear_int8<f16_t>(X, M, K, W, scales, N, bias, out, ws, ws_bytes, st);
@@ -750,6 +757,10 @@ int linear_int8_dispatch(const void *X, int dtype, int64_t M, int64_t K, const i
 // LinearFP8.forward / matmul_fp8_e4m3 (functional.py:796-807): the same W8A16 kernels with the FP8 byte decoder
 int linear_fp8_dispatch(const void *X, int dtype, int64_t M, int64_t K, const uint8_t *W, const float *scales, int64_t N,
                         const void *bias, void *out, void *workspace, int64_t ws_bytes, hipStream_t st) {
+    {
+        const int rc = linear8_dense_path(X, dtype, M, K, W, scales, N, true, bias, out, workspace, ws_bytes, st);
+        if (rc != 1) return rc;
+    }
     float *ws = static_cast<float *>(workspace);
     const int8_t *w = reinterpret_cast<const int8_t *>(W);
     switch (dtype) {

@@ -553,6 +553,37 @@ __global__ __launch_bounds__(256) void k_dequantize_rowwise(const int8_t *__rest
     out[i] = from_f32<T>((float)q[i] * s);
 }
 
+// 16 consecutive elements of one row per thread (cols % 16 == 0, 16-byte aligned q / out): one 16-byte load, the same
+// per-element arithmetic as the scalar kernels above (bit-identical), 16-byte stores.  FP8: the byte is an E4M3 code.
+template <typename T, bool FP8>
+__global__ __launch_bounds__(256) void k_dequantize_rows16(const uint8_t *__restrict__ q, const float *__restrict__ scales, int64_t rows,
+                                                          int64_t cols, T *__restrict__ out) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+    if (i >= rows * cols) return;
+    const float sc = scales[i / cols];
+    const float s = FP8 ? sc : sc / 127.0f;  // functional.py:635
+    const u32x4 w = *reinterpret_cast<const u32x4 *>(q + i);
+    float v[16];
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+        const uint32_t b = (w[e >> 2] >> (8 * (e & 3))) & 0xFFu;
+        v[e] = FP8 ? fp8_e4m3_to_float((uint8_t)b) * s : (float)(int)(int8_t)b * s;
+    }
+    if constexpr (sizeof(T) == 2) {
+        u32x4 o0, o1;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            o0[e] = pack2<T>(v[2 * e], v[2 * e + 1]);
+            o1[e] = pack2<T>(v[8 + 2 * e], v[8 + 2 * e + 1]);
+        }
+        *reinterpret_cast<u32x4 *>(out + i) = o0;
+        *reinterpret_cast<u32x4 *>(out + i + 8) = o1;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 16; e += 4) *reinterpret_cast<f32x4 *>(out + i + e) = f32x4{v[e], v[e + 1], v[e + 2], v[e + 3]};
+    }
+}
+
 // =====================================================================================
 // double_quant (LLM.int8 row + column statistics)
 // =====================================================================================
@@ -749,6 +780,15 @@ int quantize_fp8_dispatch(const void *A, int dtype, int64_t rows, int64_t cols, 
 
 int dequantize_fp8_dispatch(const uint8_t *q, const float *scales, int64_t rows, int64_t cols, int out_dtype, void *out,
                             hipStream_t st) {
+    if (cols % 16 == 0 && ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(out)) & 15) == 0 && rows * cols > 0) {
+        const unsigned g16 = (unsigned)((rows * cols / 16 + 255) / 256);
+        switch (out_dtype) {
+            case MBNB_F16: hipLaunchKernelGGL((k_dequantize_rows16<f16_t, true>), dim3(g16), dim3(256), 0, st, q, scales, rows, cols, static_cast<f16_t *>(out)); break;
+            case MBNB_BF16: hipLaunchKernelGGL((k_dequantize_rows16<bf16_t, true>), dim3(g16), dim3(256), 0, st, q, scales, rows, cols, static_cast<bf16_t *>(out)); break;
+            default: hipLaunchKernelGGL((k_dequantize_rows16<float, true>), dim3(g16), dim3(256), 0, st, q, scales, rows, cols, static_cast<float *>(out)); break;
+        }
+        return check_launch("dequantize_fp8_e4m3");
+    }
     const unsigned grid = (unsigned)((rows * cols + 255) / 256);
     switch (out_dtype) {
         case MBNB_F16: hipLaunchKernelGGL(k_dequantize_fp8<f16_t>, dim3(grid), dim3(256), 0, st, q, scales, rows, cols, static_cast<f16_t *>(out)); break;
@@ -760,6 +800,16 @@ int dequantize_fp8_dispatch(const uint8_t *q, const float *scales, int64_t rows,
 
 int dequantize_rowwise_dispatch(const int8_t *q, const float *scales, int64_t rows, int64_t cols, int out_dtype,
                                 void *out, hipStream_t st) {
+    if (cols % 16 == 0 && ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(out)) & 15) == 0 && rows * cols > 0) {
+        const unsigned g16 = (unsigned)((rows * cols / 16 + 255) / 256);
+        const uint8_t *qb = reinterpret_cast<const uint8_t *>(q);
+        switch (out_dtype) {
+            case MBNB_F16: hipLaunchKernelGGL((k_dequantize_rows16<f16_t, false>), dim3(g16), dim3(256), 0, st, qb, scales, rows, cols, static_cast<f16_t *>(out)); break;
+            case MBNB_BF16: hipLaunchKernelGGL((k_dequantize_rows16<bf16_t, false>), dim3(g16), dim3(256), 0, st, qb, scales, rows, cols, static_cast<bf16_t *>(out)); break;
+            default: hipLaunchKernelGGL((k_dequantize_rows16<float, false>), dim3(g16), dim3(256), 0, st, qb, scales, rows, cols, static_cast<float *>(out)); break;
+        }
+        return check_launch("dequantize_rowwise");
+    }
     const unsigned grid = (unsigned)((rows * cols + 255) / 256);
     switch (out_dtype) {
         case MBNB_F16: hipLaunchKernelGGL(k_dequantize_rowwise<f16_t>, dim3(grid), dim3(256), 0, st, q, scales, rows, cols, static_cast<f16_t *>(out)); break;

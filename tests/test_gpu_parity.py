@@ -481,6 +481,44 @@ def test_linear_int8_vs_oracle(shape, dt):
     assert rel_fro(y, oracle.linear_int8(x, q, s, b)) <= TOL[dt], _native.last_kernel()
 
 
+@pytest.mark.parametrize("M,N,K,dt,kern", [(2500, 2600, 192, torch.float16, "w8a16_dequant+dense"),
+                                            (4096, 4096, 1024, torch.bfloat16, "w8a16_dequant+dense"),
+                                            (1024, 4096, 2048, torch.bfloat16, "w8a16_dequant+dense_splitk")])
+def test_linear_int8_decode_once_path(M, N, K, dt, kern, monkeypatch):
+    """Linear8bit.forward at large M: dequantize_rowwise into the workspace + k_gemm_dense; parity vs the oracle and equality
+    with the fused W8A16 256 x 256 kernel (same B-operand bits) where that one serves the shape."""
+    W = synthetic.normal((N, K), dt, seed=90, std=0.05)
+    q, s = oracle.quantize_rowwise(W)
+    x = synthetic.normal((M, K), dt, seed=91)
+    b = synthetic.normal((N,), dt, seed=92)
+    args = (x.to(DEV), q.to(DEV), s.to(DEV), b.to(DEV))
+    y = bnb.linear_int8(*args)
+    assert _native.last_kernel() == kern
+    rows = torch.arange(0, M, max(1, M // 64))[:64]
+    assert rel_fro(y.cpu()[rows], oracle.linear_int8(x[rows], q, s, b)) <= TOL[dt]
+    # the weight the GEMM saw is dequantize_rowwise's, bit for bit
+    wd = bnb.dequantize_rowwise(q.to(DEV), s.to(DEV), dt)
+    assert torch.equal(wd.cpu(), oracle.dequantize_rowwise(q, s, dt))
+    monkeypatch.setattr(bnb.functional, "DECODE_ONCE", False)
+    yf = bnb.linear_int8(*args)
+    if _native.last_kernel() == "w8a16_mfma256" and "splitk" not in kern:
+        assert torch.equal(y, yf)
+    else:
+        assert rel_fro(y, yf.cpu()) <= TOL[dt]
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("rows,cols", [(37, 4096), (5, 48), (3, 50), (1000, 1008)])
+def test_dequantize_rowwise_and_fp8_vector_and_scalar_forms_bit_exact(rows, cols, dt):
+    """dequantize_rowwise / dequantize_fp8_e4m3: the 16-elements-per-thread form (cols % 16 == 0) and the scalar form give the
+    oracle's bits."""
+    W = synthetic.normal((rows, cols), torch.float32, seed=5 + rows, std=0.3)
+    q, s = oracle.quantize_rowwise(W)
+    assert torch.equal(bnb.dequantize_rowwise(q.to(DEV), s.to(DEV), dt).cpu(), oracle.dequantize_rowwise(q, s, dt))
+    q8, s8 = oracle.quantize_fp8_e4m3(W)
+    assert torch.equal(bnb.dequantize_fp8_e4m3(q8.to(DEV), s8.to(DEV), dt).cpu(), oracle.dequantize_fp8_e4m3(q8, s8, dt))
+
+
 # --------------------------------------------------------------------------- modules
 def test_linear4bit_module_matches_oracle_and_state_dict_roundtrip():
     torch.manual_seed(0)

@@ -67,7 +67,8 @@ def test_workspace_size_functions_are_pure_host_code():
     assert sk(1024, 4096, 4096) == 2 * 256 * 65536
     assert sk(128, 4096, 72) == 0                           # K % 64 != 0
     assert sk(0, 4096, 4096) == 0
-    assert lib.mbnb_linear_int8_workspace_bytes(1024, 4096, 4096) == 2 * 256 * 65536
+    assert lib.mbnb_linear_int8_workspace_bytes(300, 4096, 4096) == sk(300, 4096, 4096) > 0
+    assert lib.mbnb_linear_int8_workspace_bytes(4096, 4096, 4096) == 4096 * 4096 * 2
     full = lib.mbnb_matmul_4bit_workspace_bytes
     assert full(128, 4096, 4096) == sk(128, 4096, 4096)     # below 512 rows: the split-K share only
     assert full(512, 4096, 4096) == sk(512, 4096, 4096)     # 32 tiles of 256^2: not yet
