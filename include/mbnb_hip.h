@@ -209,8 +209,10 @@ int mbnb_matmul_4bit_ex(const void *A, int64_t M, int64_t K, const uint8_t *pack
  * already in the compute dtype (rows ldw >= K elements apart) -- the F.linear of functional.py:767 on the tensor
  * functional.py:756 produced.  mbnb_matmul_4bit_ws calls it internally; exported for callers that keep a dequantised weight
  * (e.g. Linear4bit.dequantize(), nn/linear4bit.py:204) and for tools/.  K % 64 == 0, K >= 128, ldw % 8 == 0, A and W 16-byte
- * aligned; f32 accumulation, one rounding to `dtype`, then the cast to out_dtype.  slices > 1 splits K over
- * slices * M * N * 4 bytes of workspace (partials added in slice order); slices == 1 needs no workspace. */
+ * aligned; f32 accumulation, one rounding to `dtype`, then the cast to out_dtype.  `slices`: bits 0-7 the number of K
+ * slices (> 1 splits K over slices * M * N * 4 bytes of workspace, partials added in slice order; 1 needs no workspace);
+ * bits 8-15 the row extent of a tile in units of 128 rows: 0 = the library's choice, 1 = 256 (n) x 128 (m) tiles, 2 =
+ * 256 x 256.  The tile shape does not change the result's bits, the slice count does. */
 int mbnb_gemm_dense(const void *A, const void *W, int dtype, const void *bias, int out_dtype, void *out,
                     int64_t M, int64_t N, int64_t K, int64_t ldw, void *workspace, int64_t workspace_bytes,
                     int slices, void *stream);

@@ -73,7 +73,7 @@ int64_t matmul4_splitk_slices(int64_t, int64_t, int64_t);
 int probe_mfma_dispatch(int, int, float *, hipStream_t);
 int64_t gemm_mid_workspace_bytes(int64_t, int64_t, int64_t);
 int64_t gemm_dense_workspace_bytes(int64_t, int64_t, int64_t, int64_t);
-int gemm_dense_direct(const void *, const void *, int, const void *, int, void *, int64_t, int64_t, int64_t, int64_t, float *, int64_t,
+int gemm_dense_direct(const void *, const void *, int, const void *, int, void *, int64_t, int64_t, int64_t, int64_t, float *, int64_t, int,
                       hipStream_t);
 int matmul_int8_dispatch(const int8_t *, const int8_t *, const float *, const float *, int64_t, int64_t, int64_t, int, void *, void *, hipStream_t);
 int64_t matmul_int8_workspace_bytes(int64_t, int64_t, int64_t);
@@ -295,6 +295,10 @@ int64_t mbnb_linear_int8_workspace_bytes(int64_t M, int64_t N, int64_t K) {
 
 int mbnb_gemm_dense(const void *A, const void *W, int dtype, const void *bias, int out_dtype, void *out, int64_t M, int64_t N,
                     int64_t K, int64_t ldw, void *workspace, int64_t workspace_bytes, int slices, void *stream) {
+    // slices: bits 0-7 the K slices; bits 8-15 the row extent of a tile, 0 (library's choice), 128 or 256, in units of 128 rows
+    const int tile_m = ((slices >> 8) & 0xFF) * 128;
+    slices &= 0xFF;
+    if (tile_m != 0 && tile_m != 128 && tile_m != 256) return fail(MBNB_ERR_ARG, "gemm_dense: tile rows must be 128 or 256");
     if ((dtype != MBNB_F16 && dtype != MBNB_BF16) || !dtype_ok(out_dtype)) return fail(MBNB_ERR_ARG, "gemm_dense: bad dtype");
     if (M <= 0 || N <= 0 || K < 128 || K % 64 || ldw < K || ldw % 8) return fail(MBNB_ERR_SHAPE, "gemm_dense: bad shape");
     if (256 * ldw * 2 >= ((int64_t)1 << 31)) return fail(MBNB_ERR_SHAPE, "gemm_dense: K too large");
@@ -304,7 +308,7 @@ int mbnb_gemm_dense(const void *A, const void *W, int dtype, const void *bias, i
     if (slices < 1 || slices > 16 || (int64_t)slices * 64 > K) return fail(MBNB_ERR_ARG, "gemm_dense: bad slice count");
     if (slices > 1 && (!workspace || workspace_bytes < (int64_t)slices * M * N * 4 || (reinterpret_cast<uintptr_t>(workspace) & 15)))
         return fail(MBNB_ERR_ARG, "gemm_dense: split-K needs slices * M * N * 4 bytes of 16-byte aligned workspace");
-    return gemm_dense_direct(A, W, dtype, bias, out_dtype, out, M, N, K, ldw, static_cast<float *>(workspace), slices,
+    return gemm_dense_direct(A, W, dtype, bias, out_dtype, out, M, N, K, ldw, static_cast<float *>(workspace), slices, tile_m,
                              static_cast<hipStream_t>(stream));
 }
 

@@ -40,22 +40,40 @@ template <int N, class F> __device__ __forceinline__ void gd_static_for(F &&f) {
 }
 
 constexpr int GD_LDS = 4 * P_IMG;   // A0 A1 B0 B1; the epilogue's store staging (4 x 16.5 KiB) fits inside
-constexpr int GD_B1 = 36, GD_D0 = 36, GD_B2 = 100, GD_R0 = 100;
-static_assert(GD_D0 + 63 < GD_B2 && GD_R0 + 15 < 128, "slot plan");
 
-template <typename T, bool SPLITK>
+// Slot plan of a k-step for a wave tile of 8 (n) x FM (m) fragments of 16 x 16: NS = 16 FM slots, NR = 8 + FM fragment reads
+// per k32 slice, NP = 8 + FM LDS-DMA pieces per wave (A: FM, B: 8).
+//   FM = 8 (256 x 256 tile): reads of slice 1 every other slot from 0; B1 = 36; piece i of wave w in slot 36 + 4 i + w (one
+//           piece per slot and CU); B2 = R0 = 100; the next tile's slice-0 reads in slots 100 .. 115.
+//   FM = 4 (256 n x 128 m tile, for grids that would leave CUs idle with 256 x 256): 64 slots; reads in slots 0 .. 11;
+//           B1 = 16; piece i of wave w in slot 16 + 2 i + (w & 1) (two pieces per slot and CU); B2 = R0 = 42.
+template <int FM> struct GdPlan {
+    static constexpr int NS = 16 * FM, NR = 8 + FM, NP = 8 + FM;
+    static constexpr int RS1 = FM == 8 ? 2 : 1;                  // slot stride of the slice-1 reads
+    static constexpr int B1 = FM == 8 ? 36 : 16, D0 = B1;
+    static constexpr int DS = FM == 8 ? 4 : 2;                    // slot stride of a wave's pieces; wave offset = w & (DS - 1)
+    static constexpr int B2 = FM == 8 ? 100 : 42, R0 = B2;
+    static_assert((NR - 1) * RS1 < B1, "slice 1 is in registers before barrier 1");
+    static_assert(D0 + NP * DS <= B2, "every piece is issued before the vmcnt of barrier 2");
+    static_assert(R0 + NR <= NS, "the next tile's slice 0 is in registers before the k-step ends");
+};
+
+template <typename T, bool SPLITK, int FM = 8>
 __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, const T *__restrict__ Wd, const T *__restrict__ bias,
                                                        void *__restrict__ out_v, int out_dtype, float *__restrict__ partial,
                                                        int64_t M, int64_t N, int64_t K, int64_t ldw, int64_t k_per_slice) {
     using Frag = typename Mfma16<T>::frag;
+    using Plan = GdPlan<FM>;
+    constexpr int TM = 32 * FM;                 // rows of A per tile: two waves of 16 FM
+    constexpr int PM = FM == 8 ? 4 : 8, PN = 32 / PM;   // XCD patch of 32 tiles: the one with the smallest operand perimeter
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave >> 1, wm = wave & 1;
 
-    // ---- tile -> workgroup map (as k_gemm256s): blocks b, b+8, ... share an XCD's L2 -> compact 4 (m) x 8 (n) patches
-    const int64_t tiles_m = (M + 255) >> 8, tiles_n = (N + 255) >> 8;
+    // ---- tile -> workgroup map (as k_gemm256s): blocks b, b+8, ... share an XCD's L2 -> compact PM (m) x PN (n) patches
+    const int64_t tiles_m = (M + TM - 1) / TM, tiles_n = (N + 255) >> 8;
     const int64_t nwg = tiles_m * tiles_n;
     int64_t bid = blockIdx.x;
     int slice = 0;
@@ -68,21 +86,21 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, 
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
     }
     int64_t tm, tn;
-    if ((tiles_m % 4 == 0) && (tiles_n % 8 == 0)) {
+    if ((tiles_m % PM == 0) && (tiles_n % PN == 0)) {
         const int64_t patch = bid >> 5, within = bid & 31;
-        const int64_t patches_m = tiles_m >> 2;
-        tm = (patch % patches_m) * 4 + (within & 3);
-        tn = (patch / patches_m) * 8 + (within >> 2);
+        const int64_t patches_m = tiles_m / PM;
+        tm = (patch % patches_m) * PM + (within % PM);
+        tn = (patch / patches_m) * PN + (within / PM);
     } else {
         tm = bid % tiles_m;
         tn = bid / tiles_m;
     }
-    const int64_t m0 = tm << 8, n0 = tn << 8;
+    const int64_t m0 = tm * TM, n0 = tn << 8;
     const int64_t k_begin = SPLITK ? (int64_t)slice * k_per_slice : 0;
     const int64_t k_len = SPLITK ? (K - k_begin < k_per_slice ? K - k_begin : k_per_slice) : K;
     const int nk = (int)(k_len >> 6);
 
-    // ---- LDS-DMA: wave w moves A pieces 8w..8w+7 and B pieces 8w..8w+7 (8 rows x 128 B each).  Piece p, lane l: row
+    // ---- LDS-DMA: wave w moves A pieces FM w .. FM w + FM-1 and B pieces 8w..8w+7 (8 rows x 128 B each).  Piece p, lane l: row
     // 8p + (l >> 3), source chunk (l & 7) ^ ((row >> 1) & 7).  The ROW goes into the per-lane offset (8 + 8 VGPRs that never
     // change), the k position into the scalar offset: the descriptor's range check covers the per-lane offset only
     // (the scalar offset is excluded from it), and num_records = rows x pitch makes every row past M / N read as zeros
@@ -91,23 +109,26 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, 
     i32x4_t rs_a, rs_b;
     {
         const uint64_t pa = reinterpret_cast<uint64_t>(X + m0 * K + k_begin), pb = reinterpret_cast<uint64_t>(Wd + n0 * ldw + k_begin);
-        const int64_t rows_a = M - m0 < 256 ? M - m0 : 256, rows_b = N - n0 < 256 ? N - n0 : 256;
+        const int64_t rows_a = M - m0 < TM ? M - m0 : TM, rows_b = N - n0 < 256 ? N - n0 : 256;
         rs_a = i32x4_t{(int)(uint32_t)pa, (int)(uint32_t)(pa >> 32), (int)(rows_a * K * 2), 0x00020000};
         rs_b = i32x4_t{(int)(uint32_t)pb, (int)(uint32_t)(pb >> 32), (int)(rows_b * ldw * 2), 0x00020000};
     }
-    int voff_a[8], voff_b[8];
+    int voff_a[FM], voff_b[8];
 #pragma unroll
     for (int pl = 0; pl < 8; pl++) {
         const int row = 8 * (8 * wave + pl) + (lane >> 3);
-        const int c16 = 16 * ((lane & 7) ^ ((row >> 1) & 7));
-        voff_a[pl] = (int)(row * K * 2) + c16;
-        voff_b[pl] = (int)(row * ldw * 2) + c16;
+        voff_b[pl] = (int)(row * ldw * 2) + 16 * ((lane & 7) ^ ((row >> 1) & 7));
+    }
+#pragma unroll
+    for (int pl = 0; pl < FM; pl++) {
+        const int row = 8 * (FM * wave + pl) + (lane >> 3);
+        voff_a[pl] = (int)(row * K * 2) + 16 * ((lane & 7) ^ ((row >> 1) & 7));
     }
     const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)smem;
     // The wave-uniform operands of the DMA travel in a DmaCtx made INSIDE the loop copy that uses them: defined there by
     // readfirstlane they are SGPRs for certain (across the per-wave branch the compiler otherwise re-derives them in
     // VGPRs, which the "s" operands of the instruction cannot take).
-    struct DmaCtx { i32x4_t ra, rb; uint32_t lw; };
+    struct DmaCtx { i32x4_t ra, rb; uint32_t lwa, lwb; };
     auto dma_ctx = [&]() {
         DmaCtx c;
 #pragma unroll
@@ -115,15 +136,16 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, 
             c.ra[e] = __builtin_amdgcn_readfirstlane(rs_a[e]);
             c.rb[e] = __builtin_amdgcn_readfirstlane(rs_b[e]);
         }
-        c.lw = (uint32_t)__builtin_amdgcn_readfirstlane((int)(smem_base + (uint32_t)wave * 8192u));
+        c.lwa = (uint32_t)__builtin_amdgcn_readfirstlane((int)(smem_base + (uint32_t)(P_A + wave * FM * 1024)));
+        c.lwb = (uint32_t)__builtin_amdgcn_readfirstlane((int)(smem_base + (uint32_t)(P_B + wave * 8192)));
         return c;
     };
-    // piece q of the wave's 16 (0-7: A, 8-15: B) of the tile at byte position kb of the slice into stage `stage`
+    // piece q of the wave's NP (0 .. FM-1: A, FM .. FM+7: B) of the tile at byte position kb of the slice into stage `stage`
     auto issue_piece = [&](auto qq, int stage, int kb, const DmaCtx &c) {
-        constexpr int q = decltype(qq)::value, pl = q & 7;
-        const uint32_t dst = c.lw + (uint32_t)((q < 8 ? P_A : P_B) + stage * P_IMG + pl * 1024);
-        const int vo = (q < 8) ? voff_a[pl] : voff_b[pl];
-        const i32x4_t rs = (q < 8) ? c.ra : c.rb;
+        constexpr int q = decltype(qq)::value, pl = q < FM ? q : q - FM;
+        const uint32_t dst = (q < FM ? c.lwa : c.lwb) + (uint32_t)(stage * P_IMG + pl * 1024);
+        const int vo = (q < FM) ? voff_a[pl] : voff_b[pl];
+        const i32x4_t rs = (q < FM) ? c.ra : c.rb;
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(vo), "s"(rs), "s"(kb) : "memory", "m0");
     };
 
@@ -134,45 +156,45 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, 
     for (int ks = 0; ks < 2; ks++) {
         const int f = r16 * ROW_BYTES + (((4 * ks + fq) ^ (r16 >> 1)) << 4);
         fw[ks] = P_B + wn * 128 * ROW_BYTES + f;
-        fx[ks] = P_A + wm * 128 * ROW_BYTES + f;
+        fx[ks] = P_A + wm * 16 * FM * ROW_BYTES + f;
     }
-    Frag wf[2][8], xf[2][8];     // [k32 slice][16-row fragment]
-    // read n of a slice, in the order the MFMAs want them: w0, x0..x7, w1..w7
+    Frag wf[2][8], xf[2][FM];     // [k32 slice][16-row fragment]
+    // read n of a slice, in the order the MFMAs want them: w0, x0 .. x(FM-1), w1 .. w7
     auto read_one = [&](int stage, auto kk, auto nn) {
         constexpr int ks = decltype(kk)::value, n = decltype(nn)::value;
         if constexpr (n == 0) wf[ks][0] = *reinterpret_cast<const Frag *>(smem + fw[ks] + stage * P_IMG);
-        else if constexpr (n <= 8) xf[ks][n - 1] = *reinterpret_cast<const Frag *>(smem + fx[ks] + stage * P_IMG + (n - 1) * 16 * ROW_BYTES);
-        else wf[ks][n - 8] = *reinterpret_cast<const Frag *>(smem + fw[ks] + stage * P_IMG + (n - 8) * 16 * ROW_BYTES);
+        else if constexpr (n <= FM) xf[ks][n - 1] = *reinterpret_cast<const Frag *>(smem + fx[ks] + stage * P_IMG + (n - 1) * 16 * ROW_BYTES);
+        else wf[ks][n - FM] = *reinterpret_cast<const Frag *>(smem + fw[ks] + stage * P_IMG + (n - FM) * 16 * ROW_BYTES);
     };
-    f32x4 acc[8][8];   // never zero-filled: the first k-step's slice-0 MFMAs take a literal-zero C operand
+    f32x4 acc[8][FM];   // never zero-filled: the first k-step's slice-0 MFMAs take a literal-zero C operand
 
     auto kbytes = [&](int t) { return (t < nk ? t : nk - 1) << 7; };   // past the end: the last tile again (never used)
 
     // ---- prologue: tile 0 -> stage 0, tile 1 -> stage 1; slice 0 of tile 0 -> registers
     {
         const DmaCtx c0 = dma_ctx();
-        gd_static_for<16>([&](auto q) { issue_piece(q, 0, 0, c0); });
-        gd_static_for<16>([&](auto q) { issue_piece(q, 1, kbytes(1), c0); });
+        gd_static_for<Plan::NP>([&](auto q) { issue_piece(q, 0, 0, c0); });
+        gd_static_for<Plan::NP>([&](auto q) { issue_piece(q, 1, kbytes(1), c0); });
     }
-    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Plan::NP) : "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    gd_static_for<16>([&](auto n) { read_one(0, std::integral_constant<int, 0>{}, n); });
+    gd_static_for<Plan::NR>([&](auto n) { read_one(0, std::integral_constant<int, 0>{}, n); });
 
-    // ---- one k-step = 128 fenced slots.  Stage C holds tile j, stage Nn tile j+1 (landing); WO = the wave's slot offset.
+    // ---- one k-step = Plan::NS fenced slots.  Stage C holds tile j, stage Nn tile j+1 (landing); WO = the wave's slot offset.
     auto kstep = [&](auto cc, auto first, auto wo_, int j, const DmaCtx &dc) {
         constexpr int C = decltype(cc)::value, Nn = C ^ 1, WO = decltype(wo_)::value;
         constexpr bool FIRST = decltype(first)::value;
         const int kb2 = __builtin_amdgcn_readfirstlane(kbytes(j + 2));
-        gd_static_for<128>([&](auto tt) {
-            constexpr int t = decltype(tt)::value, ks = t >> 6, f = (t & 63) >> 3, g = t & 7;
-            if constexpr (t == GD_B1) {
+        gd_static_for<Plan::NS>([&](auto tt) {
+            constexpr int t = decltype(tt)::value, ks = t / (8 * FM), f = (t % (8 * FM)) / FM, g = t % FM;
+            if constexpr (t == Plan::B1) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
             }
-            if constexpr (t == GD_B2) {
-                asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            if constexpr (t == Plan::B2) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Plan::NP) : "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
             }
@@ -182,10 +204,12 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, 
             } else {
                 acc[f][g] = Mfma16<T>::run(wf[ks][f], xf[ks][g], acc[f][g]);
             }
-            if constexpr ((t & 1) == 0 && t < 32) read_one(C, std::integral_constant<int, 1>{}, std::integral_constant<int, (t >> 1) & 15>{});
-            if constexpr (t >= GD_R0 && t < GD_R0 + 16) read_one(Nn, std::integral_constant<int, 0>{}, std::integral_constant<int, (t - GD_R0) & 15>{});
-            if constexpr (t >= GD_D0 && t < GD_D0 + 64 && ((t - GD_D0) & 3) == WO)
-                issue_piece(std::integral_constant<int, ((t - GD_D0) >> 2) & 15>{}, C, kb2, dc);
+            if constexpr ((t % Plan::RS1) == 0 && t / Plan::RS1 < Plan::NR)
+                read_one(C, std::integral_constant<int, 1>{}, std::integral_constant<int, (t / Plan::RS1) % Plan::NR>{});
+            if constexpr (t >= Plan::R0 && t < Plan::R0 + Plan::NR)
+                read_one(Nn, std::integral_constant<int, 0>{}, std::integral_constant<int, (t - Plan::R0) % Plan::NR>{});
+            if constexpr (t >= Plan::D0 && t < Plan::D0 + Plan::NP * Plan::DS && ((t - Plan::D0) % Plan::DS) == WO)
+                issue_piece(std::integral_constant<int, ((t - Plan::D0) / Plan::DS) % Plan::NP>{}, C, kb2, dc);
             __builtin_amdgcn_sched_barrier(0);
         });
     };
@@ -199,13 +223,18 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, 
         }
         if (j < nk) kstep(std::integral_constant<int, 1>{}, std::false_type{}, wo, j, dc);
     };
-    if (wave == 0) main_loop(std::integral_constant<int, 0>{});
-    else if (wave == 1) main_loop(std::integral_constant<int, 1>{});
-    else if (wave == 2) main_loop(std::integral_constant<int, 2>{});
-    else main_loop(std::integral_constant<int, 3>{});
+    if constexpr (Plan::DS == 4) {
+        if (wave == 0) main_loop(std::integral_constant<int, 0>{});
+        else if (wave == 1) main_loop(std::integral_constant<int, 1>{});
+        else if (wave == 2) main_loop(std::integral_constant<int, 2>{});
+        else main_loop(std::integral_constant<int, 3>{});
+    } else {
+        if ((wave & 1) == 0) main_loop(std::integral_constant<int, 0>{});
+        else main_loop(std::integral_constant<int, 1>{});
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    // ---- epilogue: acc[f][g][r] = out[m0 + 128 wm + 16 g + (lane & 15)][n0 + 128 wn + 16 f + 4 (lane >> 4) + r]
+    // ---- epilogue: acc[f][g][r] = out[m0 + 16 FM wm + 16 g + (lane & 15)][n0 + 128 wn + 16 f + 4 (lane >> 4) + r]
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -218,8 +247,8 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, 
 #pragma unroll
         for (int f = 0; f < 8; f++)
 #pragma unroll
-            for (int g = 0; g < 8; g++) {
-                const int64_t m = m0 + wm * 128 + 16 * g + er16, nn = n_base + 16 * f + 4 * efq;
+            for (int g = 0; g < FM; g++) {
+                const int64_t m = m0 + wm * 16 * FM + 16 * g + er16, nn = n_base + 16 * f + 4 * efq;
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; e++) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v[e]) : "a"(acc[f][g][e]));
@@ -233,8 +262,8 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, 
 #pragma unroll
         for (int f = 0; f < 8; f++)
 #pragma unroll
-            for (int g = 0; g < 8; g++) {
-                const int64_t m = m0 + wm * 128 + 16 * g + er16, nn = n_base + 16 * f + 4 * efq;
+            for (int g = 0; g < FM; g++) {
+                const int64_t m = m0 + wm * 16 * FM + 16 * g + er16, nn = n_base + 16 * f + 4 * efq;
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
@@ -254,9 +283,9 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, 
     char *wave_lds = smem + wave * 64 * ROWB;
     uint16_t *out = static_cast<uint16_t *>(out_v);
     const bool vec_ok = (N % 8 == 0) && ((reinterpret_cast<uintptr_t>(out_v) & 15) == 0);
-    gd_static_for<2>([&](auto hh) {
+    gd_static_for<FM / 4>([&](auto hh) {
         constexpr int H = decltype(hh)::value;
-        const int64_t m_base = m0 + wm * 128 + 64 * H;
+        const int64_t m_base = m0 + wm * 16 * FM + 64 * H;
 #pragma unroll
         for (int f = 0; f < 8; f++) {
             const int nl = 16 * f + 4 * efq;

@@ -12,33 +12,39 @@ namespace mbnb {
 
 int dequantize_4bit_dispatch(const uint8_t *, const AbsmaxView &, int64_t, int64_t, int64_t, int, int, int, void *, hipStream_t);
 
-// The policy, from tools/exp/sweep_dense.py (profiles/r02_dense_sweep.txt).  The path is taken from 40 output tiles of
-// 256 x 256 and 512 rows up (below that the fused split-K kernels win: 512 x 4096 x 4096 runs 41 us fused, 49 us here).
-// Slices: the count that minimises   rounds(s) * k_steps(s) * 1.3 us  +  (s > 1) * 8 s M N bytes / 6 TB/s
-// -- workgroup rounds on 256 CUs times the measured k-step, plus the f32 partials written once and read once (what makes
-// split-K expensive here: two slices of a 4096 x 4096 output move 256 MB, 36 us measured).  The model reproduces the
-// measured best slice count on every shape of the sweep.
-int64_t gemm_dense_slices(int64_t M, int64_t N, int64_t K) {
-    const int64_t tiles = ((M + 255) / 256) * ((N + 255) / 256);
-    // From 96 tiles up never split, although two slices measure up to 13 % faster at 96-128 tiles: an unsplit product has the
-    // same bits for a row whatever M it is computed in, which is what lets row shards and row chunks of a large batch
-    // (sharding.py, bench.py --gpus N --verify) be compared bit for bit with the unsharded result.
-    if (tiles >= 96) return 1;
+// The policy, from tools/exp/sweep_dense.py (profiles/r02_dense_sweep.txt, profiles/r02_dense_sweep2.txt).  The path is taken
+// from 40 output tiles of 256 x 256 and 512 rows up (below that the fused split-K kernels win: 512 x 4096 x 4096 runs 41 us
+// fused, 49 us here).  A plan = (wave-tile m fragments FM: 8 -> 256 x 256 tiles, 4 -> 256 n x 128 m tiles; K slices s), the
+// pair minimising     rounds(FM, s) * k_steps(s) * step(FM)  +  (s > 1) * 8 s M N bytes / 6 TB/s
+// -- workgroup rounds on 256 CUs times the measured k-step (1.3 us / 0.75 us), plus the f32 partials written once and read
+// once (what makes split-K expensive here: two slices of a 4096 x 4096 output move 256 MB, 36 us measured).
+// From 96 tiles of 256 x 256 up never split, although two slices measure up to 13 % faster at 96-128 tiles: an unsplit product
+// has the same bits for a row whatever M it is computed in (the tile shape does not change a row's summation order, the
+// slice count does), which is what lets row shards and row chunks of a large batch (sharding.py, bench.py --gpus N
+// --verify) be compared bit for bit with the unsharded result.
+struct DensePlan { int fm; int64_t slices; };
+DensePlan gemm_dense_plan(int64_t M, int64_t N, int64_t K) {
+    const int64_t tn = (N + 255) / 256, tiles8 = ((M + 255) / 256) * tn, tiles4 = ((M + 127) / 128) * tn;
     const int64_t steps = K / 64;
-    int64_t best = 1;
+    DensePlan best{8, 1};
     double best_t = 1e30;
-    for (int64_t s = 1; s <= 8; s++) {
-        const int64_t per = (steps + s - 1) / s;
-        if (s > 1 && per < 8) break;
-        const int64_t rounds = (tiles * s + 255) / 256;
-        const double t = (double)rounds * (double)per * 1.3 + (s > 1 ? 8.0 * (double)s * (double)M * (double)N / 6.0e6 : 0.0);
-        if (t < best_t) {
-            best_t = t;
-            best = s;
+    for (int fm = 8; fm >= 4; fm -= 4) {
+        const int64_t tiles = fm == 8 ? tiles8 : tiles4;
+        const double step = fm == 8 ? 1.3 : 0.75;
+        for (int64_t s = 1; s <= 8; s++) {
+            const int64_t per = (steps + s - 1) / s;
+            if (s > 1 && (per < 8 || tiles8 >= 96)) break;
+            const int64_t rounds = (tiles * s + 255) / 256;
+            const double t = (double)rounds * (double)per * step + (s > 1 ? 8.0 * (double)s * (double)M * (double)N / 6.0e6 : 0.0);
+            if (t < best_t * (fm == 8 ? 1.0 : 0.97)) {   // the smaller tile has to win by a margin
+                best_t = t;
+                best = DensePlan{fm, s};
+            }
         }
     }
     return best;
 }
+int64_t gemm_dense_slices(int64_t M, int64_t N, int64_t K) { return gemm_dense_plan(M, N, K).slices; }
 int64_t gemm_dense_k_per_slice(int64_t K, int64_t slices) {
     const int64_t steps = K / 64;
     return ((steps + slices - 1) / slices) * 64;
@@ -56,18 +62,18 @@ int64_t gemm_dense_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t K_we
     return gemm_dense_wd_bytes(N, K_weight) + (s > 1 ? s * M * N * 4 : 0);
 }
 
-template <typename T>
-static int launch_gemm_dense(const T *x, const T *wd, const T *bias, void *out, int out_dtype, int64_t M, int64_t N, int64_t K,
-                             int64_t ldw, float *partial, int64_t slices, hipStream_t st) {
-    const int64_t tiles = ((M + 255) / 256) * ((N + 255) / 256);
+template <typename T, int FM>
+static int launch_gemm_dense_fm(const T *x, const T *wd, const T *bias, void *out, int out_dtype, int64_t M, int64_t N, int64_t K,
+                                int64_t ldw, float *partial, int64_t slices, hipStream_t st) {
+    const int64_t tiles = ((M + 32 * FM - 1) / (32 * FM)) * ((N + 255) / 256);
     if (slices <= 1) {
-        auto kern = k_gemm_dense<T, false>;
+        auto kern = k_gemm_dense<T, false, FM>;
         if (int rc = ensure_dyn_lds(reinterpret_cast<const void *>(kern), GD_LDS, "matmul_4bit(dense)")) return rc;
         hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), GD_LDS, st, x, wd, bias, out, out_dtype, static_cast<float *>(nullptr),
                            M, N, K, ldw, K);
         return check_launch("matmul_4bit(dense)");
     }
-    auto kern = k_gemm_dense<T, true>;
+    auto kern = k_gemm_dense<T, true, FM>;
     if (int rc = ensure_dyn_lds(reinterpret_cast<const void *>(kern), GD_LDS, "matmul_4bit(dense split-K)")) return rc;
     const int64_t kps = gemm_dense_k_per_slice(K, slices);
     const int64_t used = (K + kps - 1) / kps;    // no empty slice
@@ -85,6 +91,14 @@ static int launch_gemm_dense(const T *x, const T *wd, const T *bias, void *out, 
     return check_launch("matmul_4bit(dense split-K reduce)");
 }
 
+// fm: 8 / 4 as planned by gemm_dense_plan, 0 = plan here (slices then comes from the caller's workspace check)
+template <typename T>
+static int launch_gemm_dense(const T *x, const T *wd, const T *bias, void *out, int out_dtype, int64_t M, int64_t N, int64_t K,
+                             int64_t ldw, float *partial, int64_t slices, int fm, hipStream_t st) {
+    if (fm == 4) return launch_gemm_dense_fm<T, 4>(x, wd, bias, out, out_dtype, M, N, K, ldw, partial, slices, st);
+    return launch_gemm_dense_fm<T, 8>(x, wd, bias, out, out_dtype, M, N, K, ldw, partial, slices, st);
+}
+
 // Returns 1 when the path does not apply (caller falls through to the fused kernels), otherwise the launch status.
 int matmul_4bit_dense_path(const void *A, int64_t M, int64_t K, const uint8_t *packed, const AbsmaxView &am, int64_t N,
                            int64_t K_weight, int blocksize, int qt, int w_dtype, const void *bias, int out_dtype, void *out,
@@ -94,19 +108,20 @@ int matmul_4bit_dense_path(const void *A, int64_t M, int64_t K, const uint8_t *p
     if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(ws) & 255) || (reinterpret_cast<uintptr_t>(packed) & 3)) return 1;
     const int64_t wd_bytes = gemm_dense_wd_bytes(N, K_weight);
     if (ws_bytes < wd_bytes) return 1;
-    int64_t slices = gemm_dense_slices(M, N, K);
-    if (slices > 1 && ws_bytes < wd_bytes + slices * M * N * 4) slices = 1;   // a short workspace costs the split, not the path
+    DensePlan plan = gemm_dense_plan(M, N, K);
+    if (plan.slices > 1 && ws_bytes < wd_bytes + plan.slices * M * N * 4) plan.slices = 1;   // a short workspace costs the split, not the path
+    const int64_t slices = plan.slices;
     char *wsb = static_cast<char *>(ws);
     if (int rc = dequantize_4bit_dispatch(packed, am, N, K_weight, K_weight, blocksize, qt, w_dtype, wsb, st)) return rc;
     float *partial = reinterpret_cast<float *>(wsb + wd_bytes);
     int rc;
     if (w_dtype == MBNB_F16)
         rc = launch_gemm_dense<f16_t>(static_cast<const f16_t *>(A), reinterpret_cast<const f16_t *>(wsb), static_cast<const f16_t *>(bias),
-                                      out, out_dtype, M, N, K, K_weight, partial, slices, st);
+                                      out, out_dtype, M, N, K, K_weight, partial, slices, plan.fm, st);
     else
         rc = launch_gemm_dense<bf16_t>(static_cast<const bf16_t *>(A), reinterpret_cast<const bf16_t *>(wsb),
-                                       static_cast<const bf16_t *>(bias), out, out_dtype, M, N, K, K_weight, partial, slices, st);
-    set_kernel_name(slices > 1 ? "dequant+dense_splitk" : "dequant+dense");
+                                       static_cast<const bf16_t *>(bias), out, out_dtype, M, N, K, K_weight, partial, slices, plan.fm, st);
+    set_kernel_name(slices > 1 ? "dequant+dense_splitk" : "dequant+dense");   // tile shape: gemm_dense_plan (not part of the name)
     return rc;
 }
 
@@ -123,8 +138,9 @@ int linear8_dense_path(const void *X, int dtype, int64_t M, int64_t K, const voi
     if ((reinterpret_cast<uintptr_t>(X) & 15) || (reinterpret_cast<uintptr_t>(ws) & 255)) return 1;
     const int64_t wd_bytes = gemm_dense_wd_bytes(N, K);
     if (ws_bytes < wd_bytes) return 1;
-    int64_t slices = gemm_dense_slices(M, N, K);
-    if (slices > 1 && ws_bytes < wd_bytes + slices * M * N * 4) slices = 1;
+    DensePlan plan = gemm_dense_plan(M, N, K);
+    if (plan.slices > 1 && ws_bytes < wd_bytes + plan.slices * M * N * 4) plan.slices = 1;
+    const int64_t slices = plan.slices;
     char *wsb = static_cast<char *>(ws);
     const int rcq = fp8 ? dequantize_fp8_dispatch(static_cast<const uint8_t *>(W), scales, N, K, dtype, wsb, st)
                         : dequantize_rowwise_dispatch(static_cast<const int8_t *>(W), scales, N, K, dtype, wsb, st);
@@ -133,10 +149,10 @@ int linear8_dense_path(const void *X, int dtype, int64_t M, int64_t K, const voi
     int rc;
     if (dtype == MBNB_F16)
         rc = launch_gemm_dense<f16_t>(static_cast<const f16_t *>(X), reinterpret_cast<const f16_t *>(wsb), static_cast<const f16_t *>(bias),
-                                      out, dtype, M, N, K, K, partial, slices, st);
+                                      out, dtype, M, N, K, K, partial, slices, plan.fm, st);
     else
         rc = launch_gemm_dense<bf16_t>(static_cast<const bf16_t *>(X), reinterpret_cast<const bf16_t *>(wsb),
-                                       static_cast<const bf16_t *>(bias), out, dtype, M, N, K, K, partial, slices, st);
+                                       static_cast<const bf16_t *>(bias), out, dtype, M, N, K, K, partial, slices, plan.fm, st);
     set_kernel_name(fp8 ? (slices > 1 ? "fp8a16_dequant+dense_splitk" : "fp8a16_dequant+dense")
                         : (slices > 1 ? "w8a16_dequant+dense_splitk" : "w8a16_dequant+dense"));
     return rc;
@@ -144,12 +160,13 @@ int linear8_dense_path(const void *X, int dtype, int64_t M, int64_t K, const voi
 
 // diagnostic entry for tools/exp (the dense kernel alone on a caller-made Wd)
 int gemm_dense_direct(const void *A, const void *Wd, int dtype, const void *bias, int out_dtype, void *out, int64_t M, int64_t N,
-                      int64_t K, int64_t ldw, float *partial, int64_t slices, hipStream_t st) {
+                      int64_t K, int64_t ldw, float *partial, int64_t slices, int tile_m, hipStream_t st) {
+    const int fm = tile_m == 128 ? 4 : (tile_m == 256 ? 8 : gemm_dense_plan(M, N, K).fm);
     if (dtype == MBNB_F16)
         return launch_gemm_dense<f16_t>(static_cast<const f16_t *>(A), static_cast<const f16_t *>(Wd), static_cast<const f16_t *>(bias), out,
-                                        out_dtype, M, N, K, ldw, partial, slices, st);
+                                        out_dtype, M, N, K, ldw, partial, slices, fm, st);
     return launch_gemm_dense<bf16_t>(static_cast<const bf16_t *>(A), static_cast<const bf16_t *>(Wd), static_cast<const bf16_t *>(bias), out,
-                                     out_dtype, M, N, K, ldw, partial, slices, st);
+                                     out_dtype, M, N, K, ldw, partial, slices, fm, st);
 }
 
 }  // namespace mbnb

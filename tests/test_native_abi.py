@@ -74,7 +74,7 @@ def test_workspace_size_functions_are_pure_host_code():
     assert full(512, 4096, 4096) == sk(512, 4096, 4096)     # 32 tiles of 256^2: not yet
     assert full(4096, 4096, 4096) == 4096 * 4096 * 2        # the dequantised weight, no split (256 tiles)
     assert full(32768, 4096, 4096) == 4096 * 4096 * 2
-    assert full(1024, 4096, 4096) == 4096 * 4096 * 2 + 4 * 1024 * 4096 * 4   # 64 tiles -> 4 slices of f32 partials
+    assert full(1024, 4096, 4096) == 4096 * 4096 * 2 + 2 * 1024 * 4096 * 4   # 128 tiles of 256 x 128 -> 2 slices of f32 partials
     assert full(2048, 4096, 4096) == 4096 * 4096 * 2        # from 96 tiles up: never split (row bits independent of M)
     assert full(4096, 4096, 4104) == sk(4096, 4096, 4104)   # K % 64 != 0: fused kernels only
     kw = lib.mbnb_matmul_4bit_workspace_bytes_kw

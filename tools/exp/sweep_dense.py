@@ -30,6 +30,7 @@ ap.add_argument("--shapes", default="256,4096,4096;512,4096,4096;768,4096,4096;1
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--slices", default="1,2,4,8")
+ap.add_argument("--tiles", default="256,128", help="row extents of a tile to try")
 args = ap.parse_args()
 lib = _native.lib()
 dev = torch.device("cuda:0")
@@ -60,9 +61,10 @@ for shp in args.shapes.split(";"):
         rc = lib.mbnb_dequantize_4bit(packed.data_ptr(), ctypes.byref(desc), N, K, K, 64, _native.QUANT_CODE["nf4"], BF16, Wd.data_ptr(), st)
         assert rc == 0, rc
 
-    def dense(s):
+    def dense(s, tile_m=256):
         dequant()
-        rc = lib.mbnb_gemm_dense(X.data_ptr(), Wd.data_ptr(), BF16, None, BF16, out.data_ptr(), M, N, K, K, ws.data_ptr(), ws_bytes, s, st)
+        rc = lib.mbnb_gemm_dense(X.data_ptr(), Wd.data_ptr(), BF16, None, BF16, out.data_ptr(), M, N, K, K, ws.data_ptr(), ws_bytes,
+                                 s | ((tile_m // 128) << 8), st)
         assert rc == 0, rc
 
     fused()
@@ -71,15 +73,17 @@ for shp in args.shapes.split(";"):
     name_fused = _native.last_kernel()
     legs = {"fused": fused, "auto": lambda: bnb.matmul_4bit(X, packed, state), "blas": lambda: (dequant(), torch.matmul(X, Wd.t(), out=out))}
     checks = []
-    for s in [int(v) for v in args.slices.split(",")]:
-        if s > 1 and s * 512 > K:
-            continue
-        out.fill_(float("nan"))
-        dense(s)
-        torch.cuda.synchronize()
-        rel = ((out.double() - ref.double()).norm() / ref.double().norm()).item()
-        checks.append(f"s={s}: {'bit-equal' if torch.equal(out, ref) else f'rel {rel:.1e}'}")
-        legs[f"dense s={s}"] = (lambda s=s: dense(s))
+    for tile_m in [int(v) for v in args.tiles.split(",")]:
+        for s in [int(v) for v in args.slices.split(",")]:
+            if s > 1 and s * 512 > K:
+                continue
+            out.fill_(float("nan"))
+            dense(s, tile_m)
+            torch.cuda.synchronize()
+            rel = ((out.double() - ref.double()).norm() / ref.double().norm()).item()
+            tag = f"t{tile_m} s={s}"
+            checks.append(f"{tag}: {'bit-equal' if torch.equal(out, ref) else f'rel {rel:.1e}'}")
+            legs[f"dense {tag}"] = (lambda s=s, tile_m=tile_m: dense(s, tile_m))
     y = bnb.matmul_4bit(X, packed, state)
     torch.cuda.synchronize()
     auto_name = _native.last_kernel()
