@@ -187,10 +187,12 @@ int mbnb_matmul_4bit_ws(const void *A, int64_t M, int64_t K, const uint8_t *pack
  * functional.matmul_int8 (functional.py:788-793):
  *   out[M,N] = cast( int32(A[M,K] · B[K,N]) * (A_scales[m]/127) * (B_scales[n]/127) )
  * on the int8 MFMA.  B is read as the reference passes it, [K, N] row-major.  Large aligned problems (K % 128 == 0,
- * N % 16 == 0, 16-byte aligned A and B, >= 96 output tiles of 256 x 256) need NO workspace: the kernel transposes while it
- * reads its LDS image (ds_read_b64_tr_b8).  Otherwise `workspace` must hold mbnb_matmul_int8_workspace_bytes(M, N, K)
- * (= N*K) bytes, where B is first re-laid out K-contiguous; it may be reused as soon as the call's work has completed on
- * `stream`; workspace == NULL selects a slow generic kernel for those shapes.
+ * N % 16 == 0, 16-byte aligned A and B, >= 96 output tiles of 256 x 256) run WITHOUT a workspace: the kernel transposes
+ * while it reads its LDS image (ds_read_b64_tr_b8).  With a workspace of mbnb_matmul_int8_workspace_bytes(M, N, K) (= N*K)
+ * bytes, B is first re-laid out K-contiguous: for those large problems (additionally N % 64 == 0, K >= 256) that buys the
+ * four-wave pipeline of csrc/gemm_dense.h on v_mfma_i32_16x16x64_i8 (transpose + GEMM 1.3-1.4 x faster than the in-place
+ * kernel, same bits); smaller or unaligned problems need it for any MFMA kernel (workspace == NULL: slow generic kernel).
+ * The workspace may be reused as soon as the call's work has completed on `stream`.
  * ------------------------------------------------------------------------- */
 int64_t mbnb_matmul_int8_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int mbnb_matmul_int8(const int8_t *A, const int8_t *B, const float *A_scales,

@@ -58,10 +58,16 @@ template <int FM> struct GdPlan {
     static_assert(R0 + NR <= NS, "the next tile's slice 0 is in registers before the k-step ends");
 };
 
-template <typename T, bool SPLITK, int FM = 8>
+// I8 = true: the same kernel as an int8 GEMM (matmul_int8, functional.py:788-793).  X = A int8 [M, 2K bytes], Wd = B^T int8
+// [N, 2 ldw bytes] -- a row of 2K int8 moves and lands exactly like a row of K 16-bit values, and a lane's 16 bytes of a k32
+// slice are the 16 consecutive int8 of a k64 slice of v_mfma_i32_16x16x64_i8 -- T is the 16-bit container type, K and ldw count
+// byte PAIRS.  Accumulators hold the int32 sums (as raw bits); epilogue: float(sum) * (sA[m] / 127) * (sB[n] / 127), cast.
+template <typename T, bool SPLITK, int FM = 8, bool I8 = false>
 __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, const T *__restrict__ Wd, const T *__restrict__ bias,
                                                        void *__restrict__ out_v, int out_dtype, float *__restrict__ partial,
-                                                       int64_t M, int64_t N, int64_t K, int64_t ldw, int64_t k_per_slice) {
+                                                       int64_t M, int64_t N, int64_t K, int64_t ldw, int64_t k_per_slice,
+                                                       const float *__restrict__ sA, const float *__restrict__ sB) {
+    static_assert(!(I8 && SPLITK), "the int8 form is not split");
     using Frag = typename Mfma16<T>::frag;
     using Plan = GdPlan<FM>;
     constexpr int TM = 32 * FM;                 // rows of A per tile: two waves of 16 FM
@@ -198,7 +204,13 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, 
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
             }
-            if constexpr (FIRST && ks == 0) {
+            if constexpr (I8) {
+                typedef int i32x4_t __attribute__((ext_vector_type(4)));
+                i32x4_t c = {0, 0, 0, 0};
+                if constexpr (!(FIRST && ks == 0)) c = __builtin_bit_cast(i32x4_t, acc[f][g]);
+                acc[f][g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4_t, wf[ks][f]),
+                                                                                        __builtin_bit_cast(i32x4_t, xf[ks][g]), c, 0, 0, 0));
+            } else if constexpr (FIRST && ks == 0) {
                 const f32x4 zero = {0, 0, 0, 0};
                 acc[f][g] = Mfma16<T>::run(wf[ks][f], xf[ks][g], zero);
             } else {
@@ -269,8 +281,12 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, 
                 for (int e = 0; e < 4; e++) {
                     float sv;
                     asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(sv) : "a"(acc[f][g][e]));
-                    if (bias != nullptr && nn + e < N) sv += to_f32(bias[nn + e]);
-                    v[e] = to_f32(from_f32<T>(sv));
+                    if constexpr (I8) {
+                        v[e] = (float)__builtin_bit_cast(int, sv) * (sA[m < M ? m : M - 1] / 127.0f) * (sB[nn + e < N ? nn + e : N - 1] / 127.0f);
+                    } else {
+                        if (bias != nullptr && nn + e < N) sv += to_f32(bias[nn + e]);
+                        v[e] = to_f32(from_f32<T>(sv));
+                    }
                 }
                 if (m < M && nn < N) store4(o + m * N + nn, v, nn, N);
                 __builtin_amdgcn_sched_barrier(0);
@@ -289,12 +305,13 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, 
 #pragma unroll
         for (int f = 0; f < 8; f++) {
             const int nl = 16 * f + 4 * efq;
-            float bv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (bias != nullptr) {
+            float bv[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // I8: the four column scales
+            if (I8 || bias != nullptr) {
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
                     const int64_t n = n_base + nl + e;
-                    bv[e] = to_f32(bias[n < N ? n : N - 1]);
+                    if constexpr (I8) bv[e] = sB[n < N ? n : N - 1] / 127.0f;
+                    else bv[e] = to_f32(bias[n < N ? n : N - 1]);
                 }
             }
 #pragma unroll
@@ -304,7 +321,12 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, 
                 for (int e = 0; e < 4; e++) {
                     float sv;
                     asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(sv) : "a"(acc[f][4 * H + g][e]));
-                    v[e] = to_f32(from_f32<T>(sv + bv[e]));
+                    if constexpr (I8) {
+                        const int64_t m = m_base + 16 * g + er16;
+                        v[e] = (float)__builtin_bit_cast(int, sv) * (sA[m < M ? m : M - 1] / 127.0f) * bv[e];
+                    } else {
+                        v[e] = to_f32(from_f32<T>(sv + bv[e]));
+                    }
                 }
                 u32x2 pk;
                 if (out_dtype == MBNB_F16) pk = u32x2{pack2<f16_t>(v[0], v[1]), pack2<f16_t>(v[2], v[3])};

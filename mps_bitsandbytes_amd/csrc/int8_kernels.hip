@@ -505,16 +505,34 @@ int matmul_int8_nt_dispatch(const int8_t *A, const int8_t *Bt, const float *sA, 
 // matmul_int8 reads B as the reference passes it, [K, N] row-major.  Large aligned problems go straight to the 256 x 256
 // kernel's transposing-read form (no workspace); everything else is first re-laid out K-contiguous into the caller's
 // workspace (N * K bytes) or, without one, served by the generic kernel.
+bool gemm_i8_dense_shape(int64_t M, int64_t N, int64_t K);
+int launch_gemm_i8_dense(const int8_t *, const int8_t *, const float *, const float *, int64_t, int64_t, int64_t, int, void *, hipStream_t);
+
+// large problems with a caller workspace: B transposed once into it, then the four-wave pipeline of gemm_dense.h on int8
+static bool matmul_int8_dense(int64_t M, int64_t N, int64_t K) {
+    return gemm_i8_dense_shape(M, N, K) && (N % 64 == 0) && (K % 64 == 0);
+}
+
 bool matmul_int8_direct(const int8_t *A, const int8_t *B, int64_t M, int64_t N, int64_t K) {
     return (K % 128 == 0) && (N % 16 == 0) && ((M + 255) / 256) * ((N + 255) / 256) >= 96 &&
            ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0;
 }
 int64_t matmul_int8_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+    if (matmul_int8_dense(M, N, K)) return N * K;     // B^T for the dense pipeline (without it: the in-place kernel below)
     return matmul_int8_direct(nullptr, nullptr, M, N, K) ? 0 : N * K;
 }
 
 int matmul_int8_dispatch(const int8_t *A, const int8_t *B, const float *sA, const float *sB, int64_t M, int64_t N,
                          int64_t K, int out_dtype, void *out, void *workspace, hipStream_t st) {
+    if (workspace != nullptr && matmul_int8_dense(M, N, K) &&
+        ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(workspace)) & 15) == 0) {
+        int8_t *Bt = static_cast<int8_t *>(workspace);
+        hipLaunchKernelGGL(k_transpose_i8_64, dim3((unsigned)(N / 64), (unsigned)(K / 64)), dim3(256), 0, st, B, Bt, K, N);
+        if (int rc = check_launch("matmul_int8(transpose)")) return rc;
+        const int rc = launch_gemm_i8_dense(A, Bt, sA, sB, M, N, K, out_dtype, out, st);
+        set_kernel_name("i8_transpose+dense");
+        return rc;
+    }
     if (matmul_int8_direct(A, B, M, N, K)) {
         const int64_t tiles256 = ((M + 255) / 256) * ((N + 255) / 256);
         constexpr int lds256 = 4 * P_IMG;

@@ -611,6 +611,8 @@ def matmul_int8(A: Tensor, B: Tensor, A_scales: Tensor, B_scales: Tensor,
     out = torch.empty(M, N, dtype=out_dtype, device=A.device)
     # large aligned problems are read in place ([K, N] through a transposing LDS read); the rest need an N*K-byte scratch
     ws_bytes = int(_native.lib().mbnb_matmul_int8_workspace_bytes(M, N, K))
+    if not DECODE_ONCE and K % 128 == 0 and N % 16 == 0 and ((M + 255) // 256) * ((N + 255) // 256) >= 96:
+        ws_bytes = 0      # large aligned problems without scratch: B read in place as [K, N] (no transpose)
     workspace = torch.empty(ws_bytes, dtype=torch.int8, device=A.device) if ws_bytes > 0 else None
     with torch.cuda.device(A.device):
         check(_native.lib().mbnb_matmul_int8(

@@ -445,20 +445,29 @@ def test_g5_matmul_int8_and_linear8bit(golden):
 
 
 @pytest.mark.parametrize("shape", [(256, 256, 256), (200, 136, 320), (2500, 2600, 384), (2500, 2608, 384), (2560, 2560, 128),
-                                   (4096, 4096, 4096)])
+                                   (2500, 2624, 384), (4096, 4096, 4096)])
 def test_matmul_int8_mfma_exact_vs_integer_reference(shape):
     """BASELINE configs[3] (4096^3) and smaller: the int8 MFMA contraction is exact in int32, so the
     f32 result must match torch's integer matmul formula to f32 rounding.  N % 16 == 0 and K % 128 == 0 with >= 96 tiles
     take the workspace-free form (B read as [K, N] through ds_read_b64_tr_b8); (2500, 2600, 384) the transposed one."""
     M, N, K = shape
     direct = K % 128 == 0 and N % 16 == 0 and ((M + 255) // 256) * ((N + 255) // 256) >= 96
-    assert int(_native.lib().mbnb_matmul_int8_workspace_bytes(M, N, K)) == (0 if direct else N * K)
+    dense = direct and K >= 256 and N % 64 == 0      # with scratch: B transposed once + the four-wave pipeline (gemm_dense.h, I8)
+    assert int(_native.lib().mbnb_matmul_int8_workspace_bytes(M, N, K)) == (0 if direct and not dense else N * K)
     A = synthetic.int8_tensor((M, K), seed=80).to(DEV)
     B = synthetic.int8_tensor((K, N), seed=81).to(DEV)
     sa = (synthetic.normal((M,), torch.float32, seed=82).abs() + 0.5).to(DEV)
     sb = (synthetic.normal((N,), torch.float32, seed=83).abs() + 0.5).to(DEV)
     out = bnb.matmul_int8(A, B, sa, sb, torch.float32)
-    assert _native.last_kernel() == ("i8_mfma256" if M >= 2500 else "i8_mfma128")
+    assert _native.last_kernel() == ("i8_transpose+dense" if dense else "i8_mfma256" if M >= 2500 else "i8_mfma128")
+    if dense:   # the in-place kernel (no scratch) computes the same int32 sums and the same f32 products
+        bnb.functional.DECODE_ONCE = False
+        try:
+            out2 = bnb.matmul_int8(A, B, sa, sb, torch.float32)
+            assert _native.last_kernel() == "i8_mfma256"
+        finally:
+            bnb.functional.DECODE_ONCE = True
+        assert torch.equal(out, out2)
     rows = torch.arange(0, M, max(1, M // 64), device=DEV)
     exact = (A[rows].double() @ B.double())  # exact: |sum| < 2^53
     ref = exact * (sa[rows].double() / 127.0).unsqueeze(1) * (sb.double() / 127.0).unsqueeze(0)
