@@ -167,7 +167,7 @@ int mbnb_matmul_4bit(const void *A, int64_t M, int64_t K, const uint8_t *packed,
 int64_t mbnb_matmul_4bit_workspace_bytes(int64_t M, int64_t N, int64_t K);
 /* The same query for a weight whose rows are padded to K_weight > K columns (QuantState of a K that is not a multiple of
  * the blocksize; functional.py:216-223); mbnb_matmul_4bit_workspace_bytes(M, N, K) is this with K_weight = K.
- * Large M (>= 512 rows, K % 64 == 0, 16-bit weight dtype): the workspace also holds the weight dequantised ONCE,
+ * Large M (>= 256 rows and >= 1.5 M outputs, K % 64 == 0, 16-bit weight dtype): the workspace also holds the weight dequantised ONCE,
  * [N, K_weight] in the weight dtype (256-byte aligned; the bits mbnb_dequantize_4bit writes), and the product runs as a
  * dense 256 x 256 MFMA GEMM on it (csrc/gemm_dense.h) -- the fused kernels decode every weight tile once per 256 rows of A,
  * which at M = 4096 is 16 decodes of the same weight.  The reference's own large-batch path is the same two steps
@@ -229,7 +229,7 @@ int mbnb_linear_int8(const void *X, int dtype, int64_t M, int64_t K, const int8_
                      const float *W_scales, int64_t N, const void *bias, void *out, void *stream);
 
 /* linear_int8 with a workspace of mbnb_linear_int8_workspace_bytes(M, N, K) bytes (0 = not needed; 256-byte aligned):
- * split-K partials for mid-sized M; from 512 rows and 40 output tiles of 256 x 256 up the weight dequantised ONCE
+ * split-K partials for mid-sized M; from 256 rows and 1.5 M outputs up the weight dequantised ONCE
  * (dequantize_rowwise's bits, [N, K] in `dtype`) followed by the dense MFMA GEMM of csrc/gemm_dense.h -- the reference's own
  * two steps (nn/linear8bit.py:70-102).  workspace == NULL behaves exactly like mbnb_linear_int8.  mbnb_linear_fp8 takes the
  * same workspace. */

@@ -12,9 +12,8 @@ namespace mbnb {
 
 int dequantize_4bit_dispatch(const uint8_t *, const AbsmaxView &, int64_t, int64_t, int64_t, int, int, int, void *, hipStream_t);
 
-// The policy, from tools/exp/sweep_dense.py (profiles/r02_dense_sweep.txt, profiles/r02_dense_sweep2.txt).  The path is taken
-// from 40 output tiles of 256 x 256 and 512 rows up (below that the fused split-K kernels win: 512 x 4096 x 4096 runs 41 us
-// fused, 49 us here).  A plan = (wave-tile m fragments FM: 8 -> 256 x 256 tiles, 4 -> 256 n x 128 m tiles; K slices s), the
+// The policy, from tools/exp/sweep_dense.py (profiles/r02_dense_sweep.txt, r02_dense_sweep2.txt, r02_dense_sweep3.txt).  The
+// path is taken from 256 rows and 1.5 M outputs up (gemm_dense_shape; below that the fused split-K kernels win).  A plan = (wave-tile m fragments FM: 8 -> 256 x 256 tiles, 4 -> 256 n x 128 m tiles; K slices s), the
 // pair minimising     rounds(FM, s) * k_steps(s) * step(FM)  +  (s > 1) * 8 s M N bytes / 6 TB/s
 // -- workgroup rounds on 256 CUs times the measured k-step (1.3 us / 0.75 us), plus the f32 partials written once and read
 // once (what makes split-K expensive here: two slices of a 4096 x 4096 output move 256 MB, 36 us measured).
@@ -53,7 +52,8 @@ bool gemm_dense_shape(int64_t M, int64_t N, int64_t K, int64_t K_weight) {
     if (K % 64 != 0 || K < 128 || K_weight % 8 != 0) return false;
     if (256 * (K > K_weight ? K : K_weight) * 2 >= ((int64_t)1 << 31)) return false;
     if (M * N * 4 >= ((int64_t)1 << 40)) return false;
-    return M >= 512 && ((M + 255) / 256) * ((N + 255) / 256) >= 40;
+    // from 256 rows and 1.5 M outputs up (sweep3: 384 x 4096 x 4096 35.5 us here, 43.2 fused; 256 x 4096 x 4096 stays fused, 28.4 vs 33.8)
+    return M >= 256 && M * N >= 1500000;
 }
 int64_t gemm_dense_wd_bytes(int64_t N, int64_t K_weight) { return (N * K_weight * 2 + 255) & ~(int64_t)255; }
 int64_t gemm_dense_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t K_weight) {

@@ -62,7 +62,7 @@ def _check_device(tensor: Tensor, operation: str = "operation"):
 _warned: set = set()
 
 
-# matmul_4bit at >= 512 rows: let the library dequantise the weight ONCE into a transient N x K scratch (in the weight dtype)
+# matmul_4bit from 256 rows and 1.5 M outputs up: let the library dequantise the weight ONCE into a transient N x K scratch (in the weight dtype)
 # and run a dense MFMA GEMM -- what the reference does for M > 512 (functional.py:753-767) -- instead of the fused kernels,
 # which decode each weight tile once per 256 rows.  False keeps the fused kernels at every M (no N x K scratch).
 DECODE_ONCE = True
@@ -554,7 +554,7 @@ def matmul_4bit(
     keep: list = []
     desc = _absmax_desc(quant_state.absmax.to(A.device), quant_state.state2, keep)
     # The library's scratch (0 bytes = none needed for this shape): mid-sized M leaves too few output tiles for 256 CUs and
-    # K is split over f32 partials; large M (>= 512) decodes the weight ONCE into it (N x K_weight in the weight dtype) and
+    # K is split over f32 partials; large M (>= 256 rows, >= 1.5 M outputs) decodes the weight ONCE into it (N x K_weight in the weight dtype) and
     # runs a dense MFMA GEMM instead of re-decoding every weight tile per 256 rows.  torch's caching allocator makes the
     # allocation a pointer bump; the memory goes back to the pool on return.
     if DECODE_ONCE:

@@ -167,9 +167,10 @@ def test_matmul_skinny_path(case):
     dict(M=512, N=4096, K=2048, dt=torch.bfloat16, cd=torch.float32), dict(M=1024, N=2048, K=4096, dt=torch.float16),
     dict(M=40, N=11008, K=4096, dt=torch.bfloat16, cs=True, bs=32),
 ])
-def test_matmul_splitk_path(case):
+def test_matmul_splitk_path(case, monkeypatch):
     """128 x 128 tiles with K split over a caller workspace (mbnb_matmul_4bit_ws) and a deterministic slice reduction:
     M > 192 (384 for N >= 8192), or blocksize != 64 (the mid-sized-batch kernel takes the rest)."""
+    monkeypatch.setattr(bnb.functional, "DECODE_ONCE", False)   # the fused split-K kernels (callers without the N x K scratch)
     c = dict(case)
     M, N, K = c["M"], c["N"], c["K"]
     assert _oracle_vs_gpu_matmul(c.pop("M"), c.pop("N"), c.pop("K"), c.pop("dt"), seed=28, **c) == "mfma128_splitk"
@@ -191,9 +192,10 @@ def test_matmul_splitk_path(case):
     dict(M=300, N=8192, K=256, dt=torch.float16, want="mfma_mid"),                               # 4 k-steps, no split (384 tiles), wide layer
     dict(M=65, N=64, K=256, dt=torch.bfloat16, bias=False, want="mfma_mid"),                     # one tile, K too short to split
 ])
-def test_matmul_mid_batch_path(case):
+def test_matmul_mid_batch_path(case, monkeypatch):
     """k_gemm_mid (gemm_mid.h): 32 < M <= 384 at blocksize 64 -- 128 x 64 tiles, optional split-K through the caller's
     workspace (row-major f32 partials, slices added in index order)."""
+    monkeypatch.setattr(bnb.functional, "DECODE_ONCE", False)   # the fused mid-batch kernel (callers without the N x K scratch)
     c = dict(case)
     want = c.pop("want")
     M, N, K, dt = c.pop("M"), c.pop("N"), c.pop("K"), c.pop("dt")
@@ -242,6 +244,8 @@ def test_matmul_mfma256_path(case, monkeypatch):
     dict(M=1024, N=4096, K=1024, dt=torch.bfloat16, cs=True),            # split-K over f32 partials
     dict(M=768, N=4000, K=2048, dt=torch.float16, qt="fp4"),             # split-K, ragged N
     dict(M=700, N=3800, K=1088, dt=torch.bfloat16, cd=torch.float32),    # split-K with a short last slice, f32 output
+    dict(M=384, N=4096, K=4096, dt=torch.bfloat16),                      # 256 x 128 tiles, 48 of them: split-K
+    dict(M=257, N=11008, K=512, dt=torch.float16, cs=True),              # 256 x 128 tiles, ragged M (one row in the third tile)
 ])
 def test_matmul_decode_once_path(case, monkeypatch):
     """Large M through the Python API: dequantize_4bit into the scratch + k_gemm_dense (gemm_dense.h), any blocksize / code
@@ -634,7 +638,7 @@ def test_linear_int8_skinny_path(M, N, K, dt, bias):
 
 
 @pytest.mark.parametrize("M,N,K,dt,bias", [(128, 4096, 4096, torch.bfloat16, True), (300, 1000, 1024, torch.float16, False),
-                                            (1024, 2048, 2048, torch.bfloat16, True)])
+                                            (240, 2048, 2048, torch.bfloat16, True)])
 def test_linear_int8_splitk_path(M, N, K, dt, bias):
     """Linear8bit.forward for mid-sized M: 128 x 128 tiles, K split over a workspace (mbnb_linear_int8_ws)."""
     W = synthetic.normal((N, K), dt, seed=71, std=0.05)

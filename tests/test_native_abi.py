@@ -56,7 +56,7 @@ def test_argument_errors_use_status_and_last_error():
 
 def test_workspace_size_functions_are_pure_host_code():
     """Workspace policy.  Split-K share: nothing for GEMV / skinny-sized M or for shapes that fill the chip with 256 x 256
-    tiles; slices x tiles x 64 KiB (128 x 128 f32) in between.  Full query: from 512 rows and 40 tiles of 256 x 256 up the
+    tiles; slices x tiles x 64 KiB (128 x 128 f32) in between.  Full query: from 256 rows and 1.5 M outputs up the
     dequantised weight (N x K_weight x 2 bytes, 256-byte granules) plus slices x M x N f32 partials."""
     lib = _native.lib()
     sk = lib.mbnb_matmul_4bit_splitk_workspace_bytes
@@ -67,11 +67,12 @@ def test_workspace_size_functions_are_pure_host_code():
     assert sk(1024, 4096, 4096) == 2 * 256 * 65536
     assert sk(128, 4096, 72) == 0                           # K % 64 != 0
     assert sk(0, 4096, 4096) == 0
-    assert lib.mbnb_linear_int8_workspace_bytes(300, 4096, 4096) == sk(300, 4096, 4096) > 0
+    assert lib.mbnb_linear_int8_workspace_bytes(200, 4096, 4096) == sk(200, 4096, 4096) > 0
     assert lib.mbnb_linear_int8_workspace_bytes(4096, 4096, 4096) == 4096 * 4096 * 2
     full = lib.mbnb_matmul_4bit_workspace_bytes
     assert full(128, 4096, 4096) == sk(128, 4096, 4096)     # below 512 rows: the split-K share only
-    assert full(512, 4096, 4096) == sk(512, 4096, 4096)     # 32 tiles of 256^2: not yet
+    assert full(256, 4096, 4096) == sk(256, 4096, 4096)     # 1.05 M outputs: not yet
+    assert full(384, 4096, 4096) > 4096 * 4096 * 2          # 1.57 M outputs: the weight + split-K partials
     assert full(4096, 4096, 4096) == 4096 * 4096 * 2        # the dequantised weight, no split (256 tiles)
     assert full(32768, 4096, 4096) == 4096 * 4096 * 2
     assert full(1024, 4096, 4096) == 4096 * 4096 * 2 + 2 * 1024 * 4096 * 4   # 128 tiles of 256 x 128 -> 2 slices of f32 partials
