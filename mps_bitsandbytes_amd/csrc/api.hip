@@ -72,6 +72,7 @@ int linear_fp8_dispatch(const void *, int, int64_t, int64_t, const uint8_t *, co
 int64_t matmul4_splitk_slices(int64_t, int64_t, int64_t);
 int probe_mfma_dispatch(int, int, float *, hipStream_t);
 int64_t gemm_mid_workspace_bytes(int64_t, int64_t, int64_t);
+int64_t gemm_small_workspace_bytes(int64_t, int64_t, int64_t, int64_t);
 int64_t gemm_dense_workspace_bytes(int64_t, int64_t, int64_t, int64_t);
 int gemm_dense_direct(const void *, const void *, int, const void *, int, void *, int64_t, int64_t, int64_t, int64_t, float *, int64_t, int,
                       hipStream_t);
@@ -271,7 +272,9 @@ int64_t mbnb_matmul_4bit_splitk_workspace_bytes(int64_t M, int64_t N, int64_t K)
     const int64_t s = matmul4_splitk_slices(M, N, K);
     const int64_t a = s > 1 ? s * ((M + 127) / 128) * ((N + 127) / 128) * 65536 : 0;   // slices x tiles x 128 x 128 f32
     const int64_t b = gemm_mid_workspace_bytes(M, N, K);   // slices x M x N f32 (mid-sized batches, blocksize 64)
-    return a > b ? a : b;
+    const int64_t c = gemm_small_workspace_bytes(M, N, K, K);   // slices x M x N f32 (64 < M <= 256, blocksize 64)
+    const int64_t ab = a > b ? a : b;
+    return ab > c ? ab : c;
 }
 
 int64_t mbnb_matmul_4bit_workspace_bytes_kw(int64_t M, int64_t N, int64_t K, int64_t K_weight) {

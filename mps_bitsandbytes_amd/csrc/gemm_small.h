@@ -1,0 +1,268 @@
+// gemm_small.h — k_gemm_small: fused NF4/FP4 dequant + MFMA GEMM for FEW activation rows (64 < M <= 256), blocksize 64.
+//
+// Why another kernel: at these M every weight element feeds only M rows of MFMA work, a workgroup's k-steps are short, and
+// the 128 x 64 kernel of gemm_mid.h spends its k-step on LDS traffic and the barrier for the DECODED WEIGHT image (20-30 us
+// for a 4096 x 4096 layer whose weights stream in 2 us).  Here the weight never touches LDS:
+//   * workgroup = 64 weight rows (n) x one K slice x up to 128 activation rows; 4 waves, wave w owns the 16 weight rows
+//     n0 + 16 w .. + 15 and ALL the activation rows: 16 * MF (m) x 16 (n) per wave = MF accumulators of 16 x 16;
+//   * a lane decodes exactly the MFMA operand it needs, from registers to registers: for v_mfma_f32_16x16x32 lane l holds
+//     8 consecutive k of weight row l & 15; the k order inside a 256-k step is permuted so that those 8 k are one packed
+//     dword of a 16-byte load: lane (row r, kc = l >> 4) loads the 16 bytes at k = 32 (4 j + kc) .. + 31 (j = 0, 1) and uses
+//     dword s of them as the operand of MFMA slice (j, s), i.e. k = 32 (4 j + kc) + 8 s .. + 7.  The activation operand of that
+//     slice is read from LDS at the same k (chunk 16 j + 4 kc + s of the row): any permutation is free on that side;
+//   * activations: one LDS image of [16 MF rows][256 k] per stage (512-byte rows), two stages, by LDS-DMA one k-step ahead
+//     (buffer form: rows past M read as zeros); bank swizzle chunk ^ (r ^ 4 ((r >> 2 ^ r >> 3) & 1)) on the low four chunk bits
+//     makes the 16-lane groups of a ds_read_b128 conflict free (both k-chunk halves of a group land on complementary sets);
+//   * absmax: the two values a lane needs per step come straight from global (double-quantised: code + absmax2), one step ahead;
+//   * one barrier per 256-k step (64 MFMAs per wave), decode = byte table (ds_read_b64 per packed byte) * absmax in f32 -> RNE
+//     16 bit: the bits dequantize_4bit produces.
+// Split-K: grid (n tiles, slices, m tiles); f32 partials row-major into the workspace, k_splitk_reduce_rm adds them in slice
+// order.  Requirements (launcher): blocksize 64, K % 256 == 0, k_per_slice % 256 == 0 and <= 2048 (8 steps), 16-byte aligned X
+// rows / packed rows.
+#pragma once
+#include "gemm256.h"
+#include <utility>
+
+namespace mbnb {
+
+template <int... I, class F> __device__ __forceinline__ void gs_static_for_impl(std::integer_sequence<int, I...>, F &&f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F> __device__ __forceinline__ void gs_static_for(F &&f) {
+    gs_static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F &&>(f));
+}
+
+template <int MF> constexpr int gemm_small_lds_bytes() { return 2 * 16 * MF * 512; }
+
+template <typename T, bool NESTED, int MF>
+__global__ __launch_bounds__(256, 1) void k_gemm_small(const T *__restrict__ X, const uint8_t *__restrict__ packed, AbsmaxView am,
+                                                       const T *__restrict__ bias, void *__restrict__ out_v, int out_dtype,
+                                                       float *__restrict__ partial, int64_t M, int64_t N, int64_t K,
+                                                       int64_t K_weight, int64_t k_per_slice, int qt) {
+    using Frag = typename Mfma16<T>::frag;
+    constexpr int ROWS = 16 * MF, STAGE = ROWS * 512, NPW = ROWS / 8;   // rows of A per tile, bytes per stage, DMA pieces per wave
+    __shared__ __attribute__((aligned(2048))) float s_lut2[512];   // byte table: entry b = (code[b & 15], code[b >> 4])
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, kc = lane >> 4;
+    const int64_t n0 = (int64_t)blockIdx.x * 64, m0 = (int64_t)blockIdx.z * ROWS;
+    const int slice = blockIdx.y;
+    const int64_t k_begin = (int64_t)slice * k_per_slice;
+    const int64_t k_len = K - k_begin < k_per_slice ? K - k_begin : k_per_slice;
+    const int nsteps = (int)(k_len >> 8);
+
+    {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int e = tid * 2 + h, bb = e >> 1, nib = (e & 1) ? (bb >> 4) : (bb & 15);
+            float v = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+                if (nib == i) v = (qt == MBNB_NF4) ? nf4_code(i) : fp4_code(i);
+            s_lut2[e] = v;
+        }
+    }
+
+    // ---- activations by LDS-DMA: piece p = rows 2p, 2p+1 (1 KiB); wave w moves pieces NPW w .. NPW w + NPW-1.  Lane l: row
+    // 2p + (l >> 5), LDS position l & 31 holds source chunk (pos & 16) | ((pos & 15) ^ swz(row)).  Row in the per-lane offset
+    // (range-checked: rows past M read as zeros), k position in the scalar offset.
+    typedef int i32x4_t __attribute__((ext_vector_type(4)));
+    i32x4_t rs_a;
+    {
+        const uint64_t pa = reinterpret_cast<uint64_t>(X + m0 * K + k_begin);
+        const int64_t rows_a = M - m0 < ROWS ? M - m0 : ROWS;
+        rs_a = i32x4_t{(int)(uint32_t)pa, (int)(uint32_t)(pa >> 32), (int)(rows_a * K * 2), 0x00020000};
+#pragma unroll
+        for (int e = 0; e < 4; e++) rs_a[e] = __builtin_amdgcn_readfirstlane(rs_a[e]);
+    }
+    auto swz = [](int r) { return r ^ ((((r >> 2) ^ (r >> 3)) & 1) << 2); };
+    int voff[NPW];
+#pragma unroll
+    for (int i = 0; i < NPW; i++) {
+        const int row = 2 * (NPW * wave + i) + (lane >> 5), pos = lane & 31;
+        voff[i] = (int)(row * K * 2) + 16 * ((pos & 16) | ((pos & 15) ^ swz(row & 15)));
+    }
+    const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)smem;
+    const uint32_t lds_wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(smem_base + (uint32_t)(wave * NPW * 1024)));
+    auto issue_a = [&](int stage, int step) {
+        const int soff = __builtin_amdgcn_readfirstlane(step << 9);    // 256 k x 2 B (uniform; pinned in an SGPR for the "s" operand)
+#pragma unroll
+        for (int i = 0; i < NPW; i++) {
+            const uint32_t dst = lds_wave + (uint32_t)(stage * STAGE + i * 1024);
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(voff[i]), "s"(rs_a), "s"(soff) : "memory", "m0");
+        }
+    };
+
+    // ---- weights: lane (row r16 of the wave's 16, k chunk kc) -> 16 bytes at k = 32 (4 j + kc) of the step, j = 0, 1
+    int64_t nrow = n0 + 16 * wave + r16;
+    nrow = nrow < N ? nrow : N - 1;
+    const uint8_t *wrow = packed + nrow * (K_weight >> 1) + (k_begin >> 1) + 16 * kc;
+    const int64_t nblk = K_weight >> 6;
+    const int64_t am_row = nrow * nblk + (k_begin >> 6) + (kc >> 1);     // + 4 step + 2 j
+    // The loads go out from inline assembly and are waited for by hand (the vmcnt(0) at the top of a step, which carries the
+    // destination registers as operands so that no use can move above it): through the compiler its wait for the CURRENT
+    // step's weights would be a vmcnt(0) inside the step, behind the LDS-DMA of the next stage it cannot see -- i.e. every step
+    // would wait for its own prefetch.
+    struct WRegs { u32x4 w[2]; uint32_t a[2]; float a2[2]; };
+    auto load_w = [&](int step, WRegs &r) {
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const uint8_t *pw = wrow + (int64_t)step * 128 + 64 * j;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r.w[j]) : "v"(pw) : "memory");
+            const int64_t bi = am_row + 4 * step + 2 * j;
+            if constexpr (NESTED) {
+                const int8_t *pc = am.i8 + bi;
+                const float *p2 = am.am2 + bi / am.bs2;
+                asm volatile("global_load_sbyte %0, %1, off" : "=v"(r.a[j]) : "v"(pc) : "memory");
+                asm volatile("global_load_dword %0, %1, off" : "=v"(r.a2[j]) : "v"(p2) : "memory");
+            } else {
+                const float *pf = am.f32 + bi;
+                asm volatile("global_load_dword %0, %1, off" : "=v"(r.a[j]) : "v"(pf) : "memory");
+                r.a2[j] = 0.0f;
+            }
+        }
+    };
+    auto wait_all = [&](WRegs (&r)[8]) {   // every load of the prologue has landed; the registers travel through the wait
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[i].w[0]), "+v"(r[i].w[1]), "+v"(r[i].a[0]), "+v"(r[i].a[1]), "+v"(r[i].a2[0]), "+v"(r[i].a2[1])::"memory");
+    };
+    auto absmax_of = [&](const WRegs &r, float (&ra)[2]) {
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            if constexpr (NESTED) ra[j] = (float)(int)r.a[j] * (r.a2[j] / 127.0f);   // dequantize_blockwise arithmetic (functional.py:592-594)
+            else ra[j] = __builtin_bit_cast(float, r.a[j]);
+        }
+    };
+
+    // ---- activation fragment addresses: row 16 g + r16, chunk 16 j + 4 kc + s -> one register per s; g, j, stage immediates
+    int fa[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) fa[s] = r16 * 512 + 16 * ((4 * kc + s) ^ swz(r16));
+
+    f32x4 acc[MF];
+#pragma unroll
+    for (int g = 0; g < MF; g++) acc[g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    // Prologue.  The slice of a workgroup is short (<= 8 steps, the launcher's choice) and every workgroup of a K slice walks the
+    // same activation rows in step.  The weights of the WHOLE slice -- 32 bytes per lane and step -- are loaded into registers
+    // right away (64 + 16 VGPRs; in flight only until the first wait: a register with a load in flight must not be live
+    // across anything the compiler may turn into a copy, such as a loop back-edge).  (Touching the later steps' activation
+    // lines at this point to have them in L2 early was measured: no gain, 18.7 vs 17.4 us at 128 x 4096 x 4096.)
+    WRegs wr[8];
+    issue_a(0, 0);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        if (i < nsteps) {
+            load_w(i, wr[i]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                wr[i].w[j] = u32x4{0, 0, 0, 0};
+                wr[i].a[j] = 0;
+                wr[i].a2[j] = 0.0f;
+            }
+        }
+    }
+    wait_all(wr);
+
+    // One 256-k step = 8 slices (j, s) of 8 MFMAs.  One wave per SIMD: nothing hides an LDS round trip between a read and
+    // the MFMA that uses it, so the step is software-pipelined by hand -- the MF activation fragments and the byte-table
+    // lookups of slice i+1 are issued before the MFMAs of slice i, the products / packing of slice i+1 follow those MFMAs
+    // (independent VALU work the matrix pipe runs beside).
+    auto compute = [&](int stage, const WRegs &wr) {
+        const u32x4 (&rw)[2] = wr.w;
+        float ra[2];
+        absmax_of(wr, ra);
+        const char *lut2 = reinterpret_cast<const char *>(s_lut2);
+        Frag xf[2][MF];
+        f32x2 lk[2][4];
+        auto issue_x = [&](auto ii, auto pp) {
+            constexpr int i = decltype(ii)::value, P = decltype(pp)::value, j = i >> 2, sl = i & 3;
+#pragma unroll
+            for (int g = 0; g < MF; g++) xf[P][g] = *reinterpret_cast<const Frag *>(smem + stage * STAGE + fa[sl] + g * 16 * 512 + j * 256);
+        };
+        auto issue_lk = [&](auto ii, auto pp) {
+            constexpr int i = decltype(ii)::value, P = decltype(pp)::value, j = i >> 2, sl = i & 3;
+            const uint32_t w = rw[j][sl];
+#pragma unroll
+            for (int b = 0; b < 4; b++) lk[P][b] = *reinterpret_cast<const f32x2 *>(lut2 + (((w >> (8 * b)) & 0xFFu) << 3));
+        };
+        auto finish = [&](auto ii, auto pp) {
+            constexpr int i = decltype(ii)::value, P = decltype(pp)::value, j = i >> 2;
+            u32x4 o;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                float p0, p1;
+                asm("v_mul_f32 %0, %1, %2" : "=v"(p0) : "v"(lk[P][b][0]), "v"(ra[j]));
+                asm("v_mul_f32 %0, %1, %2" : "=v"(p1) : "v"(lk[P][b][1]), "v"(ra[j]));
+                o[b] = pack2<T>(p0, p1);
+            }
+            return __builtin_bit_cast(Frag, o);
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        // slice i: x fragments in xf[i & 1], lookups in lk[i & 1].  Iteration i issues the x reads of slice i+1 and the lookups
+        // of slice i+2, then runs the MFMAs of slice i beside the products / packing of slice i+1 (whose lookups went out one
+        // iteration earlier and have landed).
+        issue_lk(I0{}, I0{});
+        issue_x(I0{}, I0{});
+        issue_lk(I1{}, I1{});
+        Frag wf = finish(I0{}, I0{});
+        gs_static_for<8>([&](auto ii) {
+            constexpr int i = decltype(ii)::value, P = i & 1;
+            if constexpr (i < 7) issue_x(std::integral_constant<int, (i + 1) & 7>{}, std::integral_constant<int, P ^ 1>{});
+            Frag wn = wf;
+            if constexpr (i < 7) wn = finish(std::integral_constant<int, (i + 1) & 7>{}, std::integral_constant<int, P ^ 1>{});
+            if constexpr (i < 6) issue_lk(std::integral_constant<int, (i + 2) & 7>{}, std::integral_constant<int, P>{});
+#pragma unroll
+            for (int g = 0; g < MF; g++) acc[g] = Mfma16<T>::run(wf, xf[P][g], acc[g]);
+            wf = wn;
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+
+    // step t: activations in stage t & 1 (A(t+1) goes out at the top of step t, behind the barrier that frees its stage),
+    // weights in wr[t]
+    auto step = [&](auto tt) {
+        constexpr int TT = decltype(tt)::value;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();        // A(t) visible; every wave is done reading the other stage (step t - 1); byte table written
+        if (TT + 1 < nsteps) issue_a((TT + 1) & 1, TT + 1);
+        compute(TT & 1, wr[TT]);
+    };
+    gs_static_for<8>([&](auto tt) {
+        if (decltype(tt)::value < nsteps) step(tt);
+    });
+
+    // ---- epilogue: acc[g][r] = out[m0 + 16 g + (lane & 15)][n0 + 16 wave + 4 (lane >> 4) + r]
+    const int64_t nn = n0 + 16 * wave + 4 * kc;
+    if (partial != nullptr) {
+        float *o = partial + (int64_t)slice * M * N;
+#pragma unroll
+        for (int g = 0; g < MF; g++) {
+            const int64_t m = m0 + 16 * g + r16;
+            float v[4] = {acc[g][0], acc[g][1], acc[g][2], acc[g][3]};
+            if (m < M && nn < N) store4(o + m * N + nn, v, nn, N);
+        }
+        return;
+    }
+#pragma unroll
+    for (int g = 0; g < MF; g++) {
+        const int64_t m = m0 + 16 * g + r16;
+        if (m >= M || nn >= N) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            float sv = acc[g][e];
+            if (bias != nullptr && nn + e < N) sv += to_f32(bias[nn + e]);
+            v[e] = to_f32(from_f32<T>(sv));
+        }
+        if (out_dtype == MBNB_F32) store4(static_cast<float *>(out_v) + m * N + nn, v, nn, N);
+        else if (out_dtype == MBNB_F16) store4(static_cast<f16_t *>(out_v) + m * N + nn, v, nn, N);
+        else store4(static_cast<bf16_t *>(out_v) + m * N + nn, v, nn, N);
+    }
+}
+
+}  // namespace mbnb

@@ -173,7 +173,8 @@ def test_matmul_splitk_path(case, monkeypatch):
     monkeypatch.setattr(bnb.functional, "DECODE_ONCE", False)   # the fused split-K kernels (callers without the N x K scratch)
     c = dict(case)
     M, N, K = c["M"], c["N"], c["K"]
-    assert _oracle_vs_gpu_matmul(c.pop("M"), c.pop("N"), c.pop("K"), c.pop("dt"), seed=28, **c) == "mfma128_splitk"
+    want = "mfma_small_splitk" if (M <= 256 and c.get("bs", 64) == 64) else "mfma128_splitk"   # 64-blocksize, <= 256 rows: gemm_small.h
+    assert _oracle_vs_gpu_matmul(c.pop("M"), c.pop("N"), c.pop("K"), c.pop("dt"), seed=28, **c) == want
     # run-to-run determinism (fixed slice order, no atomics)
     W = synthetic.normal((N, K), torch.bfloat16, seed=1, std=0.05).to(DEV)
     x = synthetic.normal((M, K), torch.bfloat16, seed=2).to(DEV)
@@ -182,19 +183,22 @@ def test_matmul_splitk_path(case, monkeypatch):
 
 
 @pytest.mark.parametrize("case", [
-    dict(M=96, N=4096, K=4096, dt=torch.bfloat16, want="mfma_mid_splitk"),                       # 64 tiles x 4 slices
-    dict(M=128, N=4096, K=4096, dt=torch.float16, cs=True, want="mfma_mid_splitk"),              # double-quantised absmax
-    dict(M=190, N=1000, K=1024, dt=torch.float16, cs=True, qt="fp4", want="mfma_mid_splitk"),    # ragged M and N, FP4
-    dict(M=133, N=777, K=768, dt=torch.bfloat16, want="mfma_mid_splitk"),                        # 3 slices of 4 k-steps, odd M and N
-    dict(M=100, N=4096, K=1280, dt=torch.bfloat16, want="mfma_mid_splitk"),                      # slices of 512, 512, 256 k
-    dict(M=40, N=11008, K=4096, dt=torch.bfloat16, cs=True, want="mfma_mid_splitk"),             # too large a layer for the skinny kernel
+    dict(M=96, N=4096, K=4096, dt=torch.bfloat16, want="mfma_small_splitk"),                     # 64 n-tiles x 4 slices of 4 steps
+    dict(M=128, N=4096, K=4096, dt=torch.float16, cs=True, want="mfma_small_splitk"),            # double-quantised absmax
+    dict(M=190, N=1000, K=1024, dt=torch.float16, cs=True, qt="fp4", want="mfma_small_splitk"),  # two m-tiles, ragged M and N, FP4
+    dict(M=133, N=777, K=768, dt=torch.bfloat16, want="mfma_small_splitk"),                      # slices of 2 and 1 steps, odd M and N
+    dict(M=100, N=4096, K=1280, dt=torch.bfloat16, want="mfma_small_splitk"),                    # 5 steps over 3 slices
+    dict(M=40, N=11008, K=4096, dt=torch.bfloat16, cs=True, want="mfma_small_splitk"),           # 64-row form (MF = 4), wide layer
+    dict(M=64, N=4096, K=4096, dt=torch.bfloat16, want="mfma_small_splitk"),                     # 64-row form, full tile
+    dict(M=256, N=1024, K=2048, dt=torch.float16, bias=False, want="mfma_small_splitk"),         # two full m-tiles, 8-step slices
     dict(M=384, N=11008, K=4096, dt=torch.bfloat16, cd=torch.float32, want="mfma_mid"),          # 516 tiles: no split, f32 output
     dict(M=300, N=8192, K=256, dt=torch.float16, want="mfma_mid"),                               # 4 k-steps, no split (384 tiles), wide layer
     dict(M=65, N=64, K=256, dt=torch.bfloat16, bias=False, want="mfma_mid"),                     # one tile, K too short to split
 ])
 def test_matmul_mid_batch_path(case, monkeypatch):
-    """k_gemm_mid (gemm_mid.h): 32 < M <= 384 at blocksize 64 -- 128 x 64 tiles, optional split-K through the caller's
-    workspace (row-major f32 partials, slices added in index order)."""
+    """k_gemm_small (gemm_small.h): 32 < M <= 256 at blocksize 64 and K % 256 == 0 -- weights decoded from registers to
+    registers, K split through the caller's workspace (row-major f32 partials, slices added in index order); k_gemm_mid
+    (gemm_mid.h) for 256 < M <= 384 on wide layers and for K < 512."""
     monkeypatch.setattr(bnb.functional, "DECODE_ONCE", False)   # the fused mid-batch kernel (callers without the N x K scratch)
     c = dict(case)
     want = c.pop("want")
@@ -354,7 +358,7 @@ def test_matmul_row_independence_and_linearity_full_size():
     big = Y.abs() > 1e-2
     assert torch.equal((Yh * 2)[big], Y[big])
     # the same rows through the other kernels: GEMV (1 row), skinny MFMA (4 and 24 rows), split-K (300 rows)
-    for rows_n, kern in ((1, "gemv"), (4, "skinny_mfma16"), (24, "skinny_mfma16"), (150, "mfma_mid_splitk"), (300, "mfma128_splitk")):
+    for rows_n, kern in ((1, "gemv"), (4, "skinny_mfma16"), (24, "skinny_mfma16"), (150, "mfma_small_splitk"), (300, "mfma128_splitk")):
         yg = bnb.matmul_4bit(X[:rows_n], packed, st)
         assert _native.last_kernel() == kern
         assert rel_fro(yg, Y[:rows_n]) <= TOL[torch.float16]
