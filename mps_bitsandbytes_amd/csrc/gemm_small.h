@@ -3,8 +3,10 @@
 // Why another kernel: at these M every weight element feeds only M rows of MFMA work, a workgroup's k-steps are short, and
 // the 128 x 64 kernel of gemm_mid.h spends its k-step on LDS traffic and the barrier for the DECODED WEIGHT image (20-30 us
 // for a 4096 x 4096 layer whose weights stream in 2 us).  Here the weight never touches LDS:
-//   * workgroup = 64 weight rows (n) x one K slice x up to 128 activation rows; 4 waves, wave w owns the 16 weight rows
-//     n0 + 16 w .. + 15 and ALL the activation rows: 16 * MF (m) x 16 (n) per wave = MF accumulators of 16 x 16;
+//   * workgroup = 64 NF weight rows (n) x one K slice x up to 128 activation rows; 4 waves, wave w owns NF fragments of 16 weight
+//     rows and ALL the activation rows: NF x MF accumulators of 16 x 16.  NF = 2 halves the activation bytes a workgroup takes
+//     in per weight byte -- the kernel is bound by that inflow (64 n-tiles x 1 MB of activations at M = 128 on a 4096 x 4096
+//     layer = 64 MB through the L2 -> LDS path) -- and the fragment reads per MFMA;
 //   * a lane decodes exactly the MFMA operand it needs, from registers to registers: for v_mfma_f32_16x16x32 lane l holds
 //     8 consecutive k of weight row l & 15; the k order inside a 256-k step is permuted so that those 8 k are one packed
 //     dword of a 16-byte load: lane (row r, kc = l >> 4) loads the 16 bytes at k = 32 (4 j + kc) .. + 31 (j = 0, 1) and uses
@@ -34,7 +36,7 @@ template <int N, class F> __device__ __forceinline__ void gs_static_for(F &&f) {
 
 template <int MF> constexpr int gemm_small_lds_bytes() { return 2 * 16 * MF * 512; }
 
-template <typename T, bool NESTED, int MF>
+template <typename T, bool NESTED, int MF, int NF = 1>
 __global__ __launch_bounds__(256, 1) void k_gemm_small(const T *__restrict__ X, const uint8_t *__restrict__ packed, AbsmaxView am,
                                                        const T *__restrict__ bias, void *__restrict__ out_v, int out_dtype,
                                                        float *__restrict__ partial, int64_t M, int64_t N, int64_t K,
@@ -46,7 +48,8 @@ __global__ __launch_bounds__(256, 1) void k_gemm_small(const T *__restrict__ X, 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, kc = lane >> 4;
-    const int64_t n0 = (int64_t)blockIdx.x * 64, m0 = (int64_t)blockIdx.z * ROWS;
+    constexpr int MAXS = NF == 1 ? 8 : 4;     // steps of a slice: its weights live in registers
+    const int64_t n0 = (int64_t)blockIdx.x * (64 * NF), m0 = (int64_t)blockIdx.z * ROWS;
     const int slice = blockIdx.y;
     const int64_t k_begin = (int64_t)slice * k_per_slice;
     const int64_t k_len = K - k_begin < k_per_slice ? K - k_begin : k_per_slice;
@@ -85,55 +88,72 @@ __global__ __launch_bounds__(256, 1) void k_gemm_small(const T *__restrict__ X, 
     }
     const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)smem;
     const uint32_t lds_wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(smem_base + (uint32_t)(wave * NPW * 1024)));
-    auto issue_a = [&](int stage, int step) {
+    auto issue_piece = [&](auto ii, int stage, int soff) __attribute__((always_inline)) {
+        constexpr int i = decltype(ii)::value;
+        const uint32_t dst = lds_wave + (uint32_t)(stage * STAGE + i * 1024);
+        const int vo = voff[i];
+        const i32x4_t rs = rs_a;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(vo), "s"(rs), "s"(soff) : "memory", "m0");
+    };
+    auto issue_a = [&](int stage, int step) __attribute__((always_inline)) {
         const int soff = __builtin_amdgcn_readfirstlane(step << 9);    // 256 k x 2 B (uniform; pinned in an SGPR for the "s" operand)
-#pragma unroll
-        for (int i = 0; i < NPW; i++) {
-            const uint32_t dst = lds_wave + (uint32_t)(stage * STAGE + i * 1024);
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(voff[i]), "s"(rs_a), "s"(soff) : "memory", "m0");
-        }
+        gs_static_for<NPW>([&](auto ii) { issue_piece(ii, stage, soff); });
     };
 
-    // ---- weights: lane (row r16 of the wave's 16, k chunk kc) -> 16 bytes at k = 32 (4 j + kc) of the step, j = 0, 1
-    int64_t nrow = n0 + 16 * wave + r16;
-    nrow = nrow < N ? nrow : N - 1;
-    const uint8_t *wrow = packed + nrow * (K_weight >> 1) + (k_begin >> 1) + 16 * kc;
+    // ---- weights: wave w owns NF fragments of 16 rows, n0 + 16 (NF w + f) + r16; lane (row r16, k chunk kc) -> 16 bytes at
+    // k = 32 (4 j + kc) of the step, j = 0, 1
+    const uint8_t *wrow[NF];
+    int64_t am_row[NF];
     const int64_t nblk = K_weight >> 6;
-    const int64_t am_row = nrow * nblk + (k_begin >> 6) + (kc >> 1);     // + 4 step + 2 j
-    // The loads go out from inline assembly and are waited for by hand (the vmcnt(0) at the top of a step, which carries the
-    // destination registers as operands so that no use can move above it): through the compiler its wait for the CURRENT
-    // step's weights would be a vmcnt(0) inside the step, behind the LDS-DMA of the next stage it cannot see -- i.e. every step
-    // would wait for its own prefetch.
-    struct WRegs { u32x4 w[2]; uint32_t a[2]; float a2[2]; };
-    auto load_w = [&](int step, WRegs &r) {
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const uint8_t *pw = wrow + (int64_t)step * 128 + 64 * j;
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r.w[j]) : "v"(pw) : "memory");
-            const int64_t bi = am_row + 4 * step + 2 * j;
-            if constexpr (NESTED) {
-                const int8_t *pc = am.i8 + bi;
-                const float *p2 = am.am2 + bi / am.bs2;
-                asm volatile("global_load_sbyte %0, %1, off" : "=v"(r.a[j]) : "v"(pc) : "memory");
-                asm volatile("global_load_dword %0, %1, off" : "=v"(r.a2[j]) : "v"(p2) : "memory");
-            } else {
-                const float *pf = am.f32 + bi;
-                asm volatile("global_load_dword %0, %1, off" : "=v"(r.a[j]) : "v"(pf) : "memory");
-                r.a2[j] = 0.0f;
+    for (int f = 0; f < NF; f++) {
+        int64_t nrow = n0 + 16 * (NF * wave + f) + r16;
+        nrow = nrow < N ? nrow : N - 1;
+        wrow[f] = packed + nrow * (K_weight >> 1) + (k_begin >> 1) + 16 * kc;
+        am_row[f] = nrow * nblk + (k_begin >> 6) + (kc >> 1);     // + 4 step + 2 j
+    }
+    // The loads go out from inline assembly and are waited for by hand (a vmcnt(0) that carries the destination registers as
+    // operands so that no use can move above it): through the compiler its wait for the CURRENT step's weights would be a
+    // vmcnt(0) inside the step, behind the LDS-DMA of the next stage it cannot see -- every step would wait for its own prefetch.
+    struct WRegs { u32x4 w[NF][2]; uint32_t a[NF][2]; float a2[NF][2]; };
+    auto load_w = [&](int step, WRegs &r) __attribute__((always_inline)) {
+        gs_static_for<NF * 2>([&](auto fj) {
+            {
+                constexpr int f = decltype(fj)::value >> 1, j = decltype(fj)::value & 1;
+                const uint8_t *pw = wrow[f] + (int64_t)step * 128 + 64 * j;
+                u32x4 &dw = r.w[f][j];
+                uint32_t &da = r.a[f][j];
+                float &d2 = r.a2[f][j];
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dw) : "v"(pw) : "memory");
+                const int64_t bi = am_row[f] + 4 * step + 2 * j;
+                if constexpr (NESTED) {
+                    const int8_t *pc = am.i8 + bi;
+                    const float *p2 = am.am2 + bi / am.bs2;
+                    asm volatile("global_load_sbyte %0, %1, off" : "=v"(da) : "v"(pc) : "memory");
+                    asm volatile("global_load_dword %0, %1, off" : "=v"(d2) : "v"(p2) : "memory");
+                } else {
+                    const float *pf = am.f32 + bi;
+                    asm volatile("global_load_dword %0, %1, off" : "=v"(da) : "v"(pf) : "memory");
+                    d2 = 0.0f;
+                }
             }
-        }
+        });
     };
-    auto wait_all = [&](WRegs (&r)[8]) {   // every load of the prologue has landed; the registers travel through the wait
-#pragma unroll
-        for (int i = 0; i < 8; i++)
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[i].w[0]), "+v"(r[i].w[1]), "+v"(r[i].a[0]), "+v"(r[i].a[1]), "+v"(r[i].a2[0]), "+v"(r[i].a2[1])::"memory");
+    auto wait_all = [&](WRegs (&r)[MAXS]) __attribute__((always_inline)) {   // every load of the prologue has landed; the registers travel through the wait
+        gs_static_for<MAXS * NF>([&](auto q) {
+            constexpr int i = decltype(q)::value / NF, f = decltype(q)::value % NF;
+            u32x4 &w0 = r[i].w[f][0], &w1 = r[i].w[f][1];
+            uint32_t &a0 = r[i].a[f][0], &a1 = r[i].a[f][1];
+            float &b0 = r[i].a2[f][0], &b1 = r[i].a2[f][1];
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(w0), "+v"(w1), "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1)::"memory");
+        });
     };
-    auto absmax_of = [&](const WRegs &r, float (&ra)[2]) {
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            if constexpr (NESTED) ra[j] = (float)(int)r.a[j] * (r.a2[j] / 127.0f);   // dequantize_blockwise arithmetic (functional.py:592-594)
-            else ra[j] = __builtin_bit_cast(float, r.a[j]);
-        }
+    auto absmax_of = [&](const WRegs &r, float (&ra)[NF][2]) __attribute__((always_inline)) {
+        gs_static_for<NF * 2>([&](auto fj) {
+            constexpr int f = decltype(fj)::value >> 1, j = decltype(fj)::value & 1;
+            if constexpr (NESTED) ra[f][j] = (float)(int)r.a[f][j] * (r.a2[f][j] / 127.0f);   // dequantize_blockwise arithmetic (functional.py:592-594)
+            else ra[f][j] = __builtin_bit_cast(float, r.a[f][j]);
+        });
     };
 
     // ---- activation fragment addresses: row 16 g + r16, chunk 16 j + 4 kc + s -> one register per s; g, j, stage immediates
@@ -141,127 +161,143 @@ __global__ __launch_bounds__(256, 1) void k_gemm_small(const T *__restrict__ X, 
 #pragma unroll
     for (int s = 0; s < 4; s++) fa[s] = r16 * 512 + 16 * ((4 * kc + s) ^ swz(r16));
 
-    f32x4 acc[MF];
+    f32x4 acc[NF][MF];
 #pragma unroll
-    for (int g = 0; g < MF; g++) acc[g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int f = 0; f < NF; f++)
+#pragma unroll
+        for (int g = 0; g < MF; g++) acc[f][g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
-    // Prologue.  The slice of a workgroup is short (<= 8 steps, the launcher's choice) and every workgroup of a K slice walks the
-    // same activation rows in step.  The weights of the WHOLE slice -- 32 bytes per lane and step -- are loaded into registers
-    // right away (64 + 16 VGPRs; in flight only until the first wait: a register with a load in flight must not be live
-    // across anything the compiler may turn into a copy, such as a loop back-edge).  (Touching the later steps' activation
-    // lines at this point to have them in L2 early was measured: no gain, 18.7 vs 17.4 us at 128 x 4096 x 4096.)
-    WRegs wr[8];
+    // Prologue.  The slice of a workgroup is short (<= MAXS steps, the launcher's choice).  Its weights -- 32 bytes per lane,
+    // fragment and step -- are loaded into registers right away (in flight only until the first wait: a register with a load in
+    // flight must not be live across anything the compiler may turn into a copy, such as a loop back-edge).  (Touching the later
+    // steps' activation lines at this point to have them in L2 early was measured: no gain, 18.7 vs 17.4 us at 128 x 4096 x 4096.)
+    WRegs wr[MAXS];
     issue_a(0, 0);
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
+    gs_static_for<MAXS>([&](auto ii) {
+        constexpr int i = decltype(ii)::value;
         if (i < nsteps) {
             load_w(i, wr[i]);
         } else {
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-                wr[i].w[j] = u32x4{0, 0, 0, 0};
-                wr[i].a[j] = 0;
-                wr[i].a2[j] = 0.0f;
-            }
+            gs_static_for<NF * 2>([&](auto fj) {
+                constexpr int f = decltype(fj)::value >> 1, j = decltype(fj)::value & 1;
+                wr[i].w[f][j] = u32x4{0, 0, 0, 0};
+                wr[i].a[f][j] = 0;
+                wr[i].a2[f][j] = 0.0f;
+            });
         }
-    }
+    });
     wait_all(wr);
 
-    // One 256-k step = 8 slices (j, s) of 8 MFMAs.  One wave per SIMD: nothing hides an LDS round trip between a read and
-    // the MFMA that uses it, so the step is software-pipelined by hand -- the MF activation fragments and the byte-table
-    // lookups of slice i+1 are issued before the MFMAs of slice i, the products / packing of slice i+1 follow those MFMAs
+    // One 256-k step = 8 slices (j, s) of NF x MF MFMAs.  One wave per SIMD: nothing hides an LDS round trip between a read and
+    // the MFMA that uses it, so the step is software-pipelined by hand -- the MF activation fragments of slice i+1 and the
+    // byte-table lookups of slice i+2 are issued before the MFMAs of slice i, the products / packing of slice i+1 follow
     // (independent VALU work the matrix pipe runs beside).
-    auto compute = [&](int stage, const WRegs &wr) {
-        const u32x4 (&rw)[2] = wr.w;
-        float ra[2];
-        absmax_of(wr, ra);
+    // next >= 0: the LDS-DMA pieces of step `next` go out into the other stage from INSIDE the step, NPW / 8 per slice behind that
+    // slice's MFMAs (all of them up front cost the wave ~16 x 80 issue cycles before its first MFMA: 2.4 -> 1.x us per step)
+    auto compute = [&](int stage, const WRegs &w, int next) __attribute__((always_inline)) {
+        const int nsoff = __builtin_amdgcn_readfirstlane((next < 0 ? 0 : next) << 9);
+        float ra[NF][2];
+        absmax_of(w, ra);
         const char *lut2 = reinterpret_cast<const char *>(s_lut2);
         Frag xf[2][MF];
-        f32x2 lk[2][4];
-        auto issue_x = [&](auto ii, auto pp) {
+        f32x2 lk[2][NF][4];
+        auto issue_x = [&](auto ii, auto pp) __attribute__((always_inline)) {
             constexpr int i = decltype(ii)::value, P = decltype(pp)::value, j = i >> 2, sl = i & 3;
 #pragma unroll
             for (int g = 0; g < MF; g++) xf[P][g] = *reinterpret_cast<const Frag *>(smem + stage * STAGE + fa[sl] + g * 16 * 512 + j * 256);
         };
-        auto issue_lk = [&](auto ii, auto pp) {
+        auto issue_lk = [&](auto ii, auto pp) __attribute__((always_inline)) {
             constexpr int i = decltype(ii)::value, P = decltype(pp)::value, j = i >> 2, sl = i & 3;
-            const uint32_t w = rw[j][sl];
+            gs_static_for<NF>([&](auto ff) {
+                constexpr int f = decltype(ff)::value;
+                const uint32_t wd = w.w[f][j][sl];
 #pragma unroll
-            for (int b = 0; b < 4; b++) lk[P][b] = *reinterpret_cast<const f32x2 *>(lut2 + (((w >> (8 * b)) & 0xFFu) << 3));
+                for (int b = 0; b < 4; b++) lk[P][f][b] = *reinterpret_cast<const f32x2 *>(lut2 + (((wd >> (8 * b)) & 0xFFu) << 3));
+            });
         };
-        auto finish = [&](auto ii, auto pp) {
+        auto finish = [&](auto ii, auto pp, Frag (&wf)[NF]) __attribute__((always_inline)) {
             constexpr int i = decltype(ii)::value, P = decltype(pp)::value, j = i >> 2;
-            u32x4 o;
+            gs_static_for<NF>([&](auto ff) {
+                constexpr int f = decltype(ff)::value;
+                u32x4 o;
 #pragma unroll
-            for (int b = 0; b < 4; b++) {
-                float p0, p1;
-                asm("v_mul_f32 %0, %1, %2" : "=v"(p0) : "v"(lk[P][b][0]), "v"(ra[j]));
-                asm("v_mul_f32 %0, %1, %2" : "=v"(p1) : "v"(lk[P][b][1]), "v"(ra[j]));
-                o[b] = pack2<T>(p0, p1);
-            }
-            return __builtin_bit_cast(Frag, o);
+                for (int b = 0; b < 4; b++) {
+                    float p0, p1;
+                    const float l0 = lk[P][f][b][0], l1 = lk[P][f][b][1], sc = ra[f][j];
+                    asm("v_mul_f32 %0, %1, %2" : "=v"(p0) : "v"(l0), "v"(sc));
+                    asm("v_mul_f32 %0, %1, %2" : "=v"(p1) : "v"(l1), "v"(sc));
+                    o[b] = pack2<T>(p0, p1);
+                }
+                wf[f] = __builtin_bit_cast(Frag, o);
+            });
         };
         using I0 = std::integral_constant<int, 0>;
         using I1 = std::integral_constant<int, 1>;
-        // slice i: x fragments in xf[i & 1], lookups in lk[i & 1].  Iteration i issues the x reads of slice i+1 and the lookups
-        // of slice i+2, then runs the MFMAs of slice i beside the products / packing of slice i+1 (whose lookups went out one
-        // iteration earlier and have landed).
         issue_lk(I0{}, I0{});
         issue_x(I0{}, I0{});
         issue_lk(I1{}, I1{});
-        Frag wf = finish(I0{}, I0{});
+        Frag wf[NF], wn[NF];
+        finish(I0{}, I0{}, wf);
         gs_static_for<8>([&](auto ii) {
             constexpr int i = decltype(ii)::value, P = i & 1;
             if constexpr (i < 7) issue_x(std::integral_constant<int, (i + 1) & 7>{}, std::integral_constant<int, P ^ 1>{});
-            Frag wn = wf;
-            if constexpr (i < 7) wn = finish(std::integral_constant<int, (i + 1) & 7>{}, std::integral_constant<int, P ^ 1>{});
+            if constexpr (i < 7) finish(std::integral_constant<int, (i + 1) & 7>{}, std::integral_constant<int, P ^ 1>{}, wn);
             if constexpr (i < 6) issue_lk(std::integral_constant<int, (i + 2) & 7>{}, std::integral_constant<int, P>{});
 #pragma unroll
-            for (int g = 0; g < MF; g++) acc[g] = Mfma16<T>::run(wf, xf[P][g], acc[g]);
-            wf = wn;
+            for (int f = 0; f < NF; f++)
+#pragma unroll
+                for (int g = 0; g < MF; g++) acc[f][g] = Mfma16<T>::run(wf[f], xf[P][g], acc[f][g]);
+            if (next >= 0) {
+                gs_static_for<NPW / 8>([&](auto pp) { issue_piece(std::integral_constant<int, i * (NPW / 8) + decltype(pp)::value>{}, stage ^ 1, nsoff); });
+            }
+            if constexpr (i < 7) {
+#pragma unroll
+                for (int f = 0; f < NF; f++) wf[f] = wn[f];
+            }
             __builtin_amdgcn_sched_barrier(0);
         });
     };
 
-    // step t: activations in stage t & 1 (A(t+1) goes out at the top of step t, behind the barrier that frees its stage),
-    // weights in wr[t]
-    auto step = [&](auto tt) {
+    // step t: activations in stage t & 1 (A(t+1) goes out during step t, behind the barrier that frees its stage), weights in wr[t]
+    auto step = [&](auto tt) __attribute__((always_inline)) {
         constexpr int TT = decltype(tt)::value;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();        // A(t) visible; every wave is done reading the other stage (step t - 1); byte table written
-        if (TT + 1 < nsteps) issue_a((TT + 1) & 1, TT + 1);
-        compute(TT & 1, wr[TT]);
+        compute(TT & 1, wr[TT], TT + 1 < nsteps ? TT + 1 : -1);
     };
-    gs_static_for<8>([&](auto tt) {
+    gs_static_for<MAXS>([&](auto tt) {
         if (decltype(tt)::value < nsteps) step(tt);
     });
 
-    // ---- epilogue: acc[g][r] = out[m0 + 16 g + (lane & 15)][n0 + 16 wave + 4 (lane >> 4) + r]
-    const int64_t nn = n0 + 16 * wave + 4 * kc;
-    if (partial != nullptr) {
-        float *o = partial + (int64_t)slice * M * N;
+    // ---- epilogue: acc[f][g][r] = out[m0 + 16 g + (lane & 15)][n0 + 16 (NF wave + f) + 4 (lane >> 4) + r]
+#pragma unroll
+    for (int f = 0; f < NF; f++) {
+        const int64_t nn = n0 + 16 * (NF * wave + f) + 4 * kc;
+        if (partial != nullptr) {
+            float *o = partial + (int64_t)slice * M * N;
+#pragma unroll
+            for (int g = 0; g < MF; g++) {
+                const int64_t m = m0 + 16 * g + r16;
+                float v[4] = {acc[f][g][0], acc[f][g][1], acc[f][g][2], acc[f][g][3]};
+                if (m < M && nn < N) store4(o + m * N + nn, v, nn, N);
+            }
+            continue;
+        }
 #pragma unroll
         for (int g = 0; g < MF; g++) {
             const int64_t m = m0 + 16 * g + r16;
-            float v[4] = {acc[g][0], acc[g][1], acc[g][2], acc[g][3]};
-            if (m < M && nn < N) store4(o + m * N + nn, v, nn, N);
-        }
-        return;
-    }
+            if (m >= M || nn >= N) continue;
+            float v[4];
 #pragma unroll
-    for (int g = 0; g < MF; g++) {
-        const int64_t m = m0 + 16 * g + r16;
-        if (m >= M || nn >= N) continue;
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            float sv = acc[g][e];
-            if (bias != nullptr && nn + e < N) sv += to_f32(bias[nn + e]);
-            v[e] = to_f32(from_f32<T>(sv));
+            for (int e = 0; e < 4; e++) {
+                float sv = acc[f][g][e];
+                if (bias != nullptr && nn + e < N) sv += to_f32(bias[nn + e]);
+                v[e] = to_f32(from_f32<T>(sv));
+            }
+            if (out_dtype == MBNB_F32) store4(static_cast<float *>(out_v) + m * N + nn, v, nn, N);
+            else if (out_dtype == MBNB_F16) store4(static_cast<f16_t *>(out_v) + m * N + nn, v, nn, N);
+            else store4(static_cast<bf16_t *>(out_v) + m * N + nn, v, nn, N);
         }
-        if (out_dtype == MBNB_F32) store4(static_cast<float *>(out_v) + m * N + nn, v, nn, N);
-        else if (out_dtype == MBNB_F16) store4(static_cast<f16_t *>(out_v) + m * N + nn, v, nn, N);
-        else store4(static_cast<bf16_t *>(out_v) + m * N + nn, v, nn, N);
     }
 }
 

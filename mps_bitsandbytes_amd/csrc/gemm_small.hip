@@ -10,48 +10,48 @@ bool gemm_small_shape(int64_t M, int64_t N, int64_t K, int64_t K_weight) {
     return (M > 32 || (M > 16 && N * K > ((int64_t)1 << 24))) && M <= 256 && K % 256 == 0 && K >= 512 && K <= 16 * 2048 && K_weight % 256 == 0 && N >= 64 &&
            256 * K * 2 < ((int64_t)1 << 31);
 }
-// K slices: the count that minimises  rounds on 256 CUs x k-steps per slice  (+ half a k-step per extra slice for its partials)
-int64_t gemm_small_slices(int64_t M, int64_t N, int64_t K) {
-    const int64_t mf = M > 64 ? 8 : 4;
-    const int64_t wgs = ((N + 63) / 64) * ((M + 16 * mf - 1) / (16 * mf));
-    const int64_t steps = K / 256;
-    int64_t best = 1;
+// Plan = (NF: n-fragments per wave -> 64 NF weight rows per workgroup; K slices).  The kernel is bound by what a workgroup takes
+// in (activation tile 16 MF rows x 256 k per step against 32 NF bytes of weights per lane), so per step a workgroup costs
+// about  0.4 us + its activation KiB / 55 GB/s  (small_check.py: 64 KiB -> 1.6 us, 32 KiB -> 1.0 us), a slice pays a prologue
+// of ~2.5 us, and every extra slice adds M x N x 4 bytes of partials written and read (6 TB/s).
+struct SmallPlan { int nf; int64_t slices; };
+SmallPlan gemm_small_plan(int64_t M, int64_t N, int64_t K) {
+    const int64_t mf = M > 64 ? 8 : 4, mt = (M + 16 * mf - 1) / (16 * mf), steps = K / 256;
+    SmallPlan best{1, 1};
     double best_t = 1e30;
-    for (int64_t s = 1; s <= 16 && s <= steps; s++) {
-        const int64_t per = (steps + s - 1) / s;
-        if (per > 8) continue;            // a slice's weights live in registers: at most 8 steps of 256 k
-        if (per < 2 && s > 1) break;
-        const double t = (double)((wgs * s + 255) / 256) * (double)per + 0.5 * (double)(s - 1);
-        if (t < best_t - 1e-9) {
-            best_t = t;
-            best = s;
+    for (int nf = 1; nf <= 1; nf++) {   // nf = 2 (128 weight rows per workgroup) measured slower on every shape of small_check.py
+        const int64_t wgs = ((N + 64 * nf - 1) / (64 * nf)) * mt, maxs = nf == 1 ? 8 : 4;
+        const double step_us = 0.4 * nf + (double)(mf * 8) / 55.0;     // KiB of activations per step = 16 mf x 512 / 1024 = 8 mf
+        for (int64_t s = 1; s <= 16 && s <= steps; s++) {
+            const int64_t per = (steps + s - 1) / s;
+            if (per > maxs) continue;
+            const double t = (double)((wgs * s + 255) / 256) * (2.5 + (double)per * step_us) + (s > 1 ? 8.0 * (double)s * (double)M * (double)N / 6.0e6 + 2.0 : 0.0);
+            if (t < best_t - 1e-9) {
+                best_t = t;
+                best = SmallPlan{nf, s};
+            }
         }
     }
     return best;
 }
+int64_t gemm_small_slices(int64_t M, int64_t N, int64_t K) { return gemm_small_plan(M, N, K).slices; }
 int64_t gemm_small_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t K_weight) {
     if (!gemm_small_shape(M, N, K, K_weight)) return 0;
     const int64_t s = gemm_small_slices(M, N, K);
     return s > 1 ? s * M * N * 4 : 0;
 }
 
-// Returns 1 when the kernel cannot serve the call (K longer than one slice of 8 steps and no workspace for the partials).
-template <typename T, typename OutT, bool NESTED, int MF>
+template <typename T, typename OutT, bool NESTED, int MF, int NF>
 static int launch_gemm_small_mf(const T *x, const uint8_t *packed, const AbsmaxView &am, const T *bias, OutT *out, int64_t M, int64_t N,
-                                int64_t K, int64_t K_weight, int qt, float *ws, int64_t ws_bytes, hipStream_t st) {
-    auto kern = k_gemm_small<T, NESTED, MF>;
+                                int64_t K, int64_t K_weight, int qt, float *ws, int64_t ws_bytes, int64_t slices, hipStream_t st) {
+    auto kern = k_gemm_small<T, NESTED, MF, NF>;
     constexpr int lds = gemm_small_lds_bytes<MF>();
     if (int rc = ensure_dyn_lds(reinterpret_cast<const void *>(kern), lds, "matmul_4bit(small)")) return rc;
-    int64_t slices = gemm_small_slices(M, N, K);
     const int64_t steps = K / 256;
-    if (slices > 1 && (ws == nullptr || ws_bytes < slices * M * N * 4 || (reinterpret_cast<uintptr_t>(ws) & 15))) {
-        if (steps > 8) return 1;      // no room for the partials and too long a K for one slice: the caller falls through
-        slices = 1;
-    }
     const int64_t kps = ((steps + slices - 1) / slices) * 256;
     const int64_t used = (K + kps - 1) / kps;
     const int od = sizeof(OutT) == 4 ? MBNB_F32 : (std::is_same<OutT, f16_t>::value ? MBNB_F16 : MBNB_BF16);
-    const dim3 grid((unsigned)((N + 63) / 64), (unsigned)used, (unsigned)((M + 16 * MF - 1) / (16 * MF)));
+    const dim3 grid((unsigned)((N + 64 * NF - 1) / (64 * NF)), (unsigned)used, (unsigned)((M + 16 * MF - 1) / (16 * MF)));
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, x, packed, am, bias, static_cast<void *>(out), od, used > 1 ? ws : nullptr, M, N, K,
                        K_weight, kps, qt);
     if (used <= 1) {
@@ -65,11 +65,23 @@ static int launch_gemm_small_mf(const T *x, const uint8_t *packed, const AbsmaxV
     return check_launch("matmul_4bit(small split-K reduce)");
 }
 
+// Returns 1 when the kernel cannot serve the call (no workspace for the partials and K too long for one slice).
 template <typename T, typename OutT, bool NESTED>
 int launch_gemm_small(const T *x, const uint8_t *packed, const AbsmaxView &am, const T *bias, OutT *out, int64_t M, int64_t N, int64_t K,
                       int64_t K_weight, int qt, float *ws, int64_t ws_bytes, hipStream_t st) {
-    if (M <= 64) return launch_gemm_small_mf<T, OutT, NESTED, 4>(x, packed, am, bias, out, M, N, K, K_weight, qt, ws, ws_bytes, st);
-    return launch_gemm_small_mf<T, OutT, NESTED, 8>(x, packed, am, bias, out, M, N, K, K_weight, qt, ws, ws_bytes, st);
+    SmallPlan plan = gemm_small_plan(M, N, K);
+    if (plan.slices > 1 && (ws == nullptr || ws_bytes < plan.slices * M * N * 4 || (reinterpret_cast<uintptr_t>(ws) & 15))) {
+        if (K / 256 > 8) return 1;
+        plan = SmallPlan{1, 1};
+    }
+#define MBNB_SMALL(MF, NF) return launch_gemm_small_mf<T, OutT, NESTED, MF, NF>(x, packed, am, bias, out, M, N, K, K_weight, qt, ws, ws_bytes, plan.slices, st)
+    if (M <= 64) {
+        if (plan.nf == 2) MBNB_SMALL(4, 2);
+        MBNB_SMALL(4, 1);
+    }
+    if (plan.nf == 2) MBNB_SMALL(8, 2);
+    MBNB_SMALL(8, 1);
+#undef MBNB_SMALL
 }
 
 #define MBNB_INST(T, OutT, NESTED)                                                                                          \
