@@ -623,7 +623,7 @@ def main():
             assert torch.equal(Yd, bnb.matmul_4bit(X, packed, state)), "dense-only launch differs from the step's output"
             d_tflops = flops_per_step / (dense_us * 1e-6) / 1e12
             out["roofline"] = {"bound": "mfma", "kernel": "k_gemm_dense", "achieved": round(d_tflops, 2), "peak": peak, "unit": "TFLOP/s",
-                               "frac": round(d_tflops / peak, 4), "traffic": traffic.get("k_gemm_dense_bytes_per_launch"),
+                               "frac": round(d_tflops / peak, 4), "traffic": traffic.get("k_gemm_dense_bytes_per_launch") if wl == "nf4_m4096" else None,
                                "kernel_us": round(dense_us, 2),
                                "kernel_us_note": "k_gemm_dense alone: HIP events around K launches on the launching stream / K, median repetition",
                                "step_us": round(kern_ms * 1e3, 2), "dequantize_us": round(deq_us, 2),

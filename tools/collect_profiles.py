@@ -88,7 +88,7 @@ if "FETCH_SIZE" in res:
     out["counters"] = res
     # HBM traffic of the GEMV (M = 1, 64 rotating layers) and of the int8 GEMM, same counters and correction
     for wl, sub, key, alg in (("nf4_m1", "k_gemv4", "k_gemv4_bytes_per_launch", 9453568),
-                              ("int8_4096", "k_gemm_i8", "k_gemm_i8_bytes_per_launch", 2 * 4096 * 4096 + 4096 * 4096 * 2 + 2 * 4096 * 4)):
+                              ("int8_4096", "k_gemm_dense", "k_gemm_i8_bytes_per_launch", 2 * 4096 * 4096 + 4096 * 4096 * 2 + 2 * 4096 * 4)):   # the int8 form of k_gemm_dense (the transpose pass is a separate kernel)
         f = kernel_counter_mean(f"{tag}_{wl}_fetch", sub, "FETCH_SIZE")
         w = kernel_counter_mean(f"{tag}_{wl}_write", sub, "WRITE_SIZE")
         if f and w:
