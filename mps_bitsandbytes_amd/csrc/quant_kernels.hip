@@ -558,9 +558,11 @@ __global__ __launch_bounds__(256) void k_dequantize_rowwise(const int8_t *__rest
 template <typename T, bool FP8>
 __global__ __launch_bounds__(256) void k_dequantize_rows16(const uint8_t *__restrict__ q, const float *__restrict__ scales, int64_t rows,
                                                           int64_t cols, T *__restrict__ out) {
-    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
-    if (i >= rows * cols) return;
-    const float sc = scales[i / cols];
+    // blockIdx.y = row, blockIdx.x = 256 groups of 16 columns: no 64-bit division per thread
+    const int64_t c0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+    if (c0 >= cols) return;
+    const int64_t i = (int64_t)blockIdx.y * cols + c0;
+    const float sc = scales[blockIdx.y];
     const float s = FP8 ? sc : sc / 127.0f;  // functional.py:635
     const u32x4 w = *reinterpret_cast<const u32x4 *>(q + i);
     float v[16];
@@ -780,8 +782,8 @@ int quantize_fp8_dispatch(const void *A, int dtype, int64_t rows, int64_t cols, 
 
 int dequantize_fp8_dispatch(const uint8_t *q, const float *scales, int64_t rows, int64_t cols, int out_dtype, void *out,
                             hipStream_t st) {
-    if (cols % 16 == 0 && ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(out)) & 15) == 0 && rows * cols > 0) {
-        const unsigned g16 = (unsigned)((rows * cols / 16 + 255) / 256);
+    if (cols % 16 == 0 && ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(out)) & 15) == 0 && rows * cols > 0 && rows < 65536) {
+        const dim3 g16((unsigned)((cols / 16 + 255) / 256), (unsigned)rows);
         switch (out_dtype) {
             case MBNB_F16: hipLaunchKernelGGL((k_dequantize_rows16<f16_t, true>), dim3(g16), dim3(256), 0, st, q, scales, rows, cols, static_cast<f16_t *>(out)); break;
             case MBNB_BF16: hipLaunchKernelGGL((k_dequantize_rows16<bf16_t, true>), dim3(g16), dim3(256), 0, st, q, scales, rows, cols, static_cast<bf16_t *>(out)); break;
@@ -800,8 +802,8 @@ int dequantize_fp8_dispatch(const uint8_t *q, const float *scales, int64_t rows,
 
 int dequantize_rowwise_dispatch(const int8_t *q, const float *scales, int64_t rows, int64_t cols, int out_dtype,
                                 void *out, hipStream_t st) {
-    if (cols % 16 == 0 && ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(out)) & 15) == 0 && rows * cols > 0) {
-        const unsigned g16 = (unsigned)((rows * cols / 16 + 255) / 256);
+    if (cols % 16 == 0 && ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(out)) & 15) == 0 && rows * cols > 0 && rows < 65536) {
+        const dim3 g16((unsigned)((cols / 16 + 255) / 256), (unsigned)rows);
         const uint8_t *qb = reinterpret_cast<const uint8_t *>(q);
         switch (out_dtype) {
             case MBNB_F16: hipLaunchKernelGGL((k_dequantize_rows16<f16_t, false>), dim3(g16), dim3(256), 0, st, qb, scales, rows, cols, static_cast<f16_t *>(out)); break;
