@@ -348,7 +348,9 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, 
 #pragma unroll
                 for (int p = 0; p < 16; p++) {
                     const int64_t m = m_base + p * 4 + (lane_e >> 4);
-                    if (m < M) *reinterpret_cast<u32x4 *>(out + m * N + n) = piece[p];
+                    // non-temporal: the tile's 128 KiB are not read again by this launch, and 256 workgroups store 32 MB at once
+                    // (measured 98.5 -> 95.6 us at 4096^3, tools/exp/ab_dense.py variants 1008 / 1040)
+                    if (m < M) __builtin_nontemporal_store(piece[p], reinterpret_cast<u32x4 *>(out + m * N + n));
                 }
             } else {
 #pragma unroll

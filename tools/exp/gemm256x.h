@@ -292,7 +292,10 @@ __global__ __launch_bounds__(256, 1) void k_gemm256x(const T *__restrict__ X, co
 #pragma unroll
                 for (int p = 0; p < 16; p++) {
                     const int64_t m = m_base + p * 4 + (lane_e >> 4);
-                    if (m < M) *reinterpret_cast<u32x4 *>(out + m * N + n) = piece[p];
+                    if (m < M) {
+                        if constexpr ((VAR & 32) != 0) __builtin_nontemporal_store(piece[p], reinterpret_cast<u32x4 *>(out + m * N + n));
+                        else *reinterpret_cast<u32x4 *>(out + m * N + n) = piece[p];
+                    }
                 }
             } else {
 #pragma unroll
