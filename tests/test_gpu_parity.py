@@ -524,6 +524,36 @@ def test_linear_int8_decode_once_path(M, N, K, dt, kern, monkeypatch):
         assert rel_fro(y, yf.cpu()) <= TOL[dt]
 
 
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K,ldw,slices,tile,odt", [(300, 520, 256, 256, 1, 0, None), (515, 1000, 640, 704, 2, 128, torch.float32),
+                                                       (1024, 768, 2048, 2048, 4, 256, None), (129, 257, 128, 136, 1, 128, torch.float16)])
+def test_gemm_dense_c_entry_point(M, N, K, ldw, slices, tile, odt, dt):
+    """mbnb_gemm_dense through the C ABI: both tile shapes, split-K over a caller workspace, a weight pitch > K, ragged M / N,
+    bias, output casts -- against a float64 product of the same 16-bit operands; and the tile shape does not change the bits."""
+    import ctypes
+    lib = _native.lib()
+    odt = odt or dt
+    X = synthetic.normal((M, K), dt, seed=301).to(DEV)
+    Wfull = synthetic.normal((N, ldw), dt, seed=302, std=0.05).to(DEV)
+    b = synthetic.normal((N,), dt, seed=303).to(DEV)
+    ws = torch.empty(max(1, slices * M * N * 4), dtype=torch.uint8, device=DEV)
+    code, ocode, sp = _native.DTYPE_CODE[dt], _native.DTYPE_CODE[odt], _native.stream_ptr(DEV)
+
+    def run(tile_rows):
+        out = torch.full((M, N), float("nan"), dtype=odt, device=DEV)
+        rc = lib.mbnb_gemm_dense(X.data_ptr(), Wfull.data_ptr(), code, b.data_ptr(), ocode, out.data_ptr(), M, N, K, ldw, ws.data_ptr(),
+                                 ws.numel(), slices | ((tile_rows // 128) << 8), sp)
+        assert rc == 0, (rc, lib.mbnb_last_error())
+        return out
+
+    y = run(tile)
+    ref = (X.double() @ Wfull[:, :K].double().t() + b.double())
+    ref = ref.to(dt).to(odt) if odt != torch.float32 else ref.to(dt).float()       # one rounding to the weight dtype, then the cast
+    assert torch.isfinite(y).all()
+    assert rel_fro(y, ref.cpu()) <= TOL[dt]
+    assert torch.equal(y, run(128)) and torch.equal(y, run(256)), "tile shape changed the result"
+
+
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("rows,cols", [(37, 4096), (5, 48), (3, 50), (1000, 1008)])
 def test_dequantize_rowwise_and_fp8_vector_and_scalar_forms_bit_exact(rows, cols, dt):

@@ -54,6 +54,24 @@ def test_argument_errors_use_status_and_last_error():
     assert lib.mbnb_outlier_linear(None, 0, 4, 64, None, None, 8, None, 2, None, None, None, None, None) == -1
 
 
+def test_gemm_dense_and_matmul_ex_argument_errors():
+    """The round-2 entry points validate before touching the device."""
+    lib = _native.lib()
+    one = ctypes.c_void_p(256)    # any non-NULL, 16-byte aligned value: validation must fail before a dereference
+    assert lib.mbnb_gemm_dense(one, one, 2, None, 1, one, 256, 256, 256, 256, None, 0, 1, None) == -1          # f32 weights
+    assert b"dtype" in lib.mbnb_last_error()
+    assert lib.mbnb_gemm_dense(one, one, 1, None, 1, one, 256, 256, 200, 200, None, 0, 1, None) == -2          # K % 64
+    assert lib.mbnb_gemm_dense(one, one, 1, None, 1, one, 256, 256, 256, 128, None, 0, 1, None) == -2          # ldw < K
+    assert lib.mbnb_gemm_dense(one, one, 1, None, 1, one, 256, 256, 256, 256, None, 0, 2, None) == -1          # split without workspace
+    assert b"workspace" in lib.mbnb_last_error()
+    assert lib.mbnb_gemm_dense(one, one, 1, None, 1, one, 256, 256, 256, 256, None, 0, 1 | (3 << 8), None) == -1   # tile rows 384
+    assert lib.mbnb_gemm_dense(ctypes.c_void_p(8), one, 1, None, 1, one, 256, 256, 256, 256, None, 0, 1, None) == -1  # misaligned A
+    rc = lib.mbnb_matmul_4bit_ex(one, 4, 64, one, None, 8, 64, 64, 0, 0, None, 0, one, None, 0, 0, None)
+    assert rc == -1 and b"absmax" in lib.mbnb_last_error()
+    rc = lib.mbnb_matmul_4bit_ex(one, 4, 64, one, None, 8, 64, 64, 0, 0, None, 0, one, None, 0, 6, None)
+    assert rc == -1 and b"flags" in lib.mbnb_last_error()
+
+
 def test_workspace_size_functions_are_pure_host_code():
     """Workspace policy.  Split-K share: nothing for GEMV / skinny-sized M or for shapes that fill the chip with 256 x 256
     tiles; slices x tiles x 64 KiB (128 x 128 f32) in between.  Full query: from 256 rows and 1.5 M outputs up the

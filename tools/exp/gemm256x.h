@@ -243,6 +243,26 @@ __global__ __launch_bounds__(256, 1) void k_gemm256x(const T *__restrict__ X, co
             }
         return;
     }
+    if constexpr ((VAR & 64) != 0) {   // experiment: no LDS staging -- 8-byte non-temporal stores straight from the accumulators
+        uint16_t *o16 = static_cast<uint16_t *>(out_v);
+#pragma unroll
+        for (int g = 0; g < 8; g++)
+#pragma unroll
+            for (int f = 0; f < 8; f++) {
+                const int64_t m = m0 + wm * 128 + 16 * g + er16, nn = n_base + 16 * f + 4 * efq;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    float sv;
+                    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(sv) : "a"(acc[f][g][e]));
+                    v[e] = to_f32(from_f32<T>(sv));
+                }
+                const u32x2 pk = u32x2{pack2<bf16_t>(v[0], v[1]), pack2<bf16_t>(v[2], v[3])};
+                if (m < M && nn + 4 <= N) __builtin_nontemporal_store(pk, reinterpret_cast<u32x2 *>(o16 + m * N + nn));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        return;
+    }
     // 16-bit outputs: the wave's tile goes through its private 16.5 KiB of LDS (264-byte row pitch) in two halves of 64 rows
     // and leaves as 16-byte stores of whole 256-byte row segments
     constexpr int ROWB = 264;

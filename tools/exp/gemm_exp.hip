@@ -123,6 +123,7 @@ extern "C" int exp_gemm256d(int variant, const void *X, const void *Wd, void *ou
         case 612: return run_v<512>(static_cast<const bf16_t *>(X), static_cast<const bf16_t *>(Wd), out, M, N, K, st);
         case 1000: return run_x<0>(static_cast<const bf16_t *>(X), static_cast<const bf16_t *>(Wd), out, M, N, K, st);
         case 1040: return run_x<40>(static_cast<const bf16_t *>(X), static_cast<const bf16_t *>(Wd), out, M, N, K, st);
+        case 1072: return run_x<72>(static_cast<const bf16_t *>(X), static_cast<const bf16_t *>(Wd), out, M, N, K, st);
         case 1008: return run_x<8>(static_cast<const bf16_t *>(X), static_cast<const bf16_t *>(Wd), out, M, N, K, st);
         case 1024: return run_x<24>(static_cast<const bf16_t *>(X), static_cast<const bf16_t *>(Wd), out, M, N, K, st);
         case 1002: return run_x<2>(static_cast<const bf16_t *>(X), static_cast<const bf16_t *>(Wd), out, M, N, K, st);
