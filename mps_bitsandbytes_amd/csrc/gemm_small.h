@@ -1,4 +1,4 @@
-// gemm_small.h — k_gemm_small: fused NF4/FP4 dequant + MFMA GEMM for FEW activation rows (64 < M <= 256), blocksize 64.
+// gemm_small.h — k_gemm_small: fused NF4/FP4 dequant + MFMA GEMM for FEW activation rows (16/32 < M <= 256), blocksize >= 32.
 //
 // Why another kernel: at these M every weight element feeds only M rows of MFMA work, a workgroup's k-steps are short, and
 // the 128 x 64 kernel of gemm_mid.h spends its k-step on LDS traffic and the barrier for the DECODED WEIGHT image (20-30 us
@@ -19,7 +19,7 @@
 //   * one barrier per 256-k step (64 MFMAs per wave), decode = byte table (ds_read_b64 per packed byte) * absmax in f32 -> RNE
 //     16 bit: the bits dequantize_4bit produces.
 // Split-K: grid (n tiles, slices, m tiles); f32 partials row-major into the workspace, k_splitk_reduce_rm adds them in slice
-// order.  Requirements (launcher): blocksize 64, K % 256 == 0, k_per_slice % 256 == 0 and <= 2048 (8 steps), 16-byte aligned X
+// order.  Requirements (launcher): blocksize >= 32, K % 256 == 0, K_weight % 256 == 0, k_per_slice % 256 == 0 and <= 2048 (8 steps), 16-byte aligned X
 // rows / packed rows.
 #pragma once
 #include "gemm256.h"
@@ -40,7 +40,7 @@ template <typename T, bool NESTED, int MF, int NF = 1>
 __global__ __launch_bounds__(256, 1) void k_gemm_small(const T *__restrict__ X, const uint8_t *__restrict__ packed, AbsmaxView am,
                                                        const T *__restrict__ bias, void *__restrict__ out_v, int out_dtype,
                                                        float *__restrict__ partial, int64_t M, int64_t N, int64_t K,
-                                                       int64_t K_weight, int64_t k_per_slice, int qt) {
+                                                       int64_t K_weight, int64_t k_per_slice, int qt, int bs_shift) {
     using Frag = typename Mfma16<T>::frag;
     constexpr int ROWS = 16 * MF, STAGE = ROWS * 512, NPW = ROWS / 8;   // rows of A per tile, bytes per stage, DMA pieces per wave
     __shared__ __attribute__((aligned(2048))) float s_lut2[512];   // byte table: entry b = (code[b & 15], code[b >> 4])
@@ -104,13 +104,14 @@ __global__ __launch_bounds__(256, 1) void k_gemm_small(const T *__restrict__ X, 
     // k = 32 (4 j + kc) of the step, j = 0, 1
     const uint8_t *wrow[NF];
     int64_t am_row[NF];
-    const int64_t nblk = K_weight >> 6;
+    const int64_t nblk = K_weight >> bs_shift;      // absmax blocks per weight row (blocksize = 1 << bs_shift >= 32: a lane's 32-k chunk
+                                                    // never straddles a block)
 #pragma unroll
     for (int f = 0; f < NF; f++) {
         int64_t nrow = n0 + 16 * (NF * wave + f) + r16;
         nrow = nrow < N ? nrow : N - 1;
         wrow[f] = packed + nrow * (K_weight >> 1) + (k_begin >> 1) + 16 * kc;
-        am_row[f] = nrow * nblk + (k_begin >> 6) + (kc >> 1);     // + 4 step + 2 j
+        am_row[f] = nrow * nblk;
     }
     // The loads go out from inline assembly and are waited for by hand (a vmcnt(0) that carries the destination registers as
     // operands so that no use can move above it): through the compiler its wait for the CURRENT step's weights would be a
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_small(const T *__restrict__ X, 
                 uint32_t &da = r.a[f][j];
                 float &d2 = r.a2[f][j];
                 asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dw) : "v"(pw) : "memory");
-                const int64_t bi = am_row[f] + 4 * step + 2 * j;
+                const int64_t bi = am_row[f] + ((k_begin + 256 * (int64_t)step + 128 * j + 32 * kc) >> bs_shift);
                 if constexpr (NESTED) {
                     const int8_t *pc = am.i8 + bi;
                     const float *p2 = am.am2 + bi / am.bs2;

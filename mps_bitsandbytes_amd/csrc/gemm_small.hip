@@ -1,4 +1,4 @@
-// gemm_small.hip — launch of k_gemm_small (gemm_small.h): fused 4-bit GEMM for 64 < M <= 256 rows, blocksize 64.
+// gemm_small.hip — launch of k_gemm_small (gemm_small.h): fused 4-bit GEMM for 16/32 < M <= 256 rows, blocksize >= 32.
 #include "gemm_small.h"
 #include "gemm_mid.h"
 
@@ -43,7 +43,7 @@ int64_t gemm_small_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t K_we
 
 template <typename T, typename OutT, bool NESTED, int MF, int NF>
 static int launch_gemm_small_mf(const T *x, const uint8_t *packed, const AbsmaxView &am, const T *bias, OutT *out, int64_t M, int64_t N,
-                                int64_t K, int64_t K_weight, int qt, float *ws, int64_t ws_bytes, int64_t slices, hipStream_t st) {
+                                int64_t K, int64_t K_weight, int qt, int bs_shift, float *ws, int64_t ws_bytes, int64_t slices, hipStream_t st) {
     auto kern = k_gemm_small<T, NESTED, MF, NF>;
     constexpr int lds = gemm_small_lds_bytes<MF>();
     if (int rc = ensure_dyn_lds(reinterpret_cast<const void *>(kern), lds, "matmul_4bit(small)")) return rc;
@@ -53,7 +53,7 @@ static int launch_gemm_small_mf(const T *x, const uint8_t *packed, const AbsmaxV
     const int od = sizeof(OutT) == 4 ? MBNB_F32 : (std::is_same<OutT, f16_t>::value ? MBNB_F16 : MBNB_BF16);
     const dim3 grid((unsigned)((N + 64 * NF - 1) / (64 * NF)), (unsigned)used, (unsigned)((M + 16 * MF - 1) / (16 * MF)));
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, x, packed, am, bias, static_cast<void *>(out), od, used > 1 ? ws : nullptr, M, N, K,
-                       K_weight, kps, qt);
+                       K_weight, kps, qt, bs_shift);
     if (used <= 1) {
         set_kernel_name("mfma_small");
         return check_launch("matmul_4bit(small)");
@@ -68,13 +68,13 @@ static int launch_gemm_small_mf(const T *x, const uint8_t *packed, const AbsmaxV
 // Returns 1 when the kernel cannot serve the call (no workspace for the partials and K too long for one slice).
 template <typename T, typename OutT, bool NESTED>
 int launch_gemm_small(const T *x, const uint8_t *packed, const AbsmaxView &am, const T *bias, OutT *out, int64_t M, int64_t N, int64_t K,
-                      int64_t K_weight, int qt, float *ws, int64_t ws_bytes, hipStream_t st) {
+                      int64_t K_weight, int qt, int bs_shift, float *ws, int64_t ws_bytes, hipStream_t st) {
     SmallPlan plan = gemm_small_plan(M, N, K);
     if (plan.slices > 1 && (ws == nullptr || ws_bytes < plan.slices * M * N * 4 || (reinterpret_cast<uintptr_t>(ws) & 15))) {
         if (K / 256 > 8) return 1;
         plan = SmallPlan{1, 1};
     }
-#define MBNB_SMALL(MF, NF) return launch_gemm_small_mf<T, OutT, NESTED, MF, NF>(x, packed, am, bias, out, M, N, K, K_weight, qt, ws, ws_bytes, plan.slices, st)
+#define MBNB_SMALL(MF, NF) return launch_gemm_small_mf<T, OutT, NESTED, MF, NF>(x, packed, am, bias, out, M, N, K, K_weight, qt, bs_shift, ws, ws_bytes, plan.slices, st)
     if (M <= 64) {
         if (plan.nf == 2) MBNB_SMALL(4, 2);
         MBNB_SMALL(4, 1);
@@ -86,7 +86,7 @@ int launch_gemm_small(const T *x, const uint8_t *packed, const AbsmaxView &am, c
 
 #define MBNB_INST(T, OutT, NESTED)                                                                                          \
     template int launch_gemm_small<T, OutT, NESTED>(const T *, const uint8_t *, const AbsmaxView &, const T *, OutT *, int64_t, \
-                                                    int64_t, int64_t, int64_t, int, float *, int64_t, hipStream_t);
+                                                    int64_t, int64_t, int64_t, int, int, float *, int64_t, hipStream_t);
 MBNB_INST(f16_t, f16_t, false) MBNB_INST(f16_t, f16_t, true) MBNB_INST(f16_t, bf16_t, false) MBNB_INST(f16_t, bf16_t, true)
 MBNB_INST(f16_t, float, false) MBNB_INST(f16_t, float, true)
 MBNB_INST(bf16_t, f16_t, false) MBNB_INST(bf16_t, f16_t, true) MBNB_INST(bf16_t, bf16_t, false) MBNB_INST(bf16_t, bf16_t, true)

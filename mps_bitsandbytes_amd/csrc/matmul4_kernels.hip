@@ -32,8 +32,8 @@ int launch_gemm_mid(const T *x, const typename Q4ProducerRT<T, NESTED>::Params &
 bool gemm_mid_shape(int64_t M, int64_t N, int64_t K);
 bool gemm_small_shape(int64_t M, int64_t N, int64_t K, int64_t K_weight);
 template <typename T, typename OutT, bool NESTED>
-int launch_gemm_small(const T *, const uint8_t *, const AbsmaxView &, const T *, OutT *, int64_t, int64_t, int64_t, int64_t, int, float *, int64_t,
-                      hipStream_t);
+int launch_gemm_small(const T *, const uint8_t *, const AbsmaxView &, const T *, OutT *, int64_t, int64_t, int64_t, int64_t, int, int, float *,
+                      int64_t, hipStream_t);
 int matmul_4bit_dense_path(const void *, int64_t, int64_t, const uint8_t *, const AbsmaxView &, int64_t, int64_t, int, int, int, const void *,
                            int, void *, void *, int64_t, hipStream_t);
 
@@ -259,7 +259,7 @@ static int launch_matmul4(const void *A, int64_t M, int64_t K, const uint8_t *pa
 #endif
         // weight-streaming regime with a few activation rows: 2 <= M <= 32, and up to 64 for layers of <= 16 Mi weights
         // (beyond that the activation re-reads of the skinny kernel cost more than split-K's second pass)
-        const bool small_ok = blocksize == 64 && gemm_small_shape(M, N, K, K_weight);   // 32 < M <= 256: gemm_small.h
+        const bool small_ok = blocksize >= 32 && gemm_small_shape(M, N, K, K_weight);   // 32 < M <= 256: gemm_small.h
         const bool skinny = fast_layout && !no_skinny && M >= 2 && !small_ok && (M <= 32 || (M <= 64 && N * K <= ((int64_t)1 << 24))) &&
                             (K % 128 == 0);
         if (fast_layout && M <= 16 && (K % 32 == 0) && !(splitk && M > 4) && !skinny) {
@@ -312,9 +312,9 @@ static int launch_matmul4(const void *A, int64_t M, int64_t K, const uint8_t *pa
             set_kernel_name("skinny_mfma16");
             return check_launch("matmul_4bit(skinny)");
         }
-        if (fast_layout && blocksize == 64 && gemm_small_shape(M, N, K, K_weight)) {
+        if (fast_layout && small_ok) {
             // 64 < M <= 256: weights decoded from registers to registers, activations by LDS-DMA (gemm_small.h)
-            const int rc = launch_gemm_small<T, OutT, NESTED>(x, packed, am, b, o, M, N, K, K_weight, QT, ws, ws_bytes, st);
+            const int rc = launch_gemm_small<T, OutT, NESTED>(x, packed, am, b, o, M, N, K, K_weight, QT, ilog2(blocksize), ws, ws_bytes, st);
             if (rc != 1) return rc;
         }
         if (fast_layout && blocksize == 64 && (K_weight % 256 == 0) && gemm_mid_shape(M, N, K)) {

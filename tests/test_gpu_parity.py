@@ -154,7 +154,7 @@ def test_matmul_gemv_path(M, dt):
     dict(M=2, N=4096, K=4096, dt=torch.bfloat16), dict(M=7, N=1000, K=384, dt=torch.float16, qt="fp4", cs=True),
     dict(M=16, N=11008, K=4096, dt=torch.bfloat16, cs=True), dict(M=17, N=48, K=128, dt=torch.float16, bs=32),
     dict(M=32, N=4096, K=1024, dt=torch.float16, cd=torch.float32), dict(M=33, N=512, K=256, dt=torch.bfloat16),
-    dict(M=64, N=4096, K=4096, dt=torch.bfloat16, bs=128),
+    dict(M=32, N=4096, K=4096, dt=torch.bfloat16, bs=128),
 ])
 def test_matmul_skinny_path(case):
     """k_skinny4: 1, 2 and 4 activation tiles of 16 rows, ragged N, nested absmax, both code tables, 1-2 blocks per wave."""
@@ -173,7 +173,7 @@ def test_matmul_splitk_path(case, monkeypatch):
     monkeypatch.setattr(bnb.functional, "DECODE_ONCE", False)   # the fused split-K kernels (callers without the N x K scratch)
     c = dict(case)
     M, N, K = c["M"], c["N"], c["K"]
-    want = "mfma_small_splitk" if (M <= 256 and c.get("bs", 64) == 64) else "mfma128_splitk"   # 64-blocksize, <= 256 rows: gemm_small.h
+    want = "mfma_small_splitk" if (M <= 256 and K % 256 == 0 and K >= 512) else "mfma128_splitk"   # <= 256 rows: gemm_small.h
     assert _oracle_vs_gpu_matmul(c.pop("M"), c.pop("N"), c.pop("K"), c.pop("dt"), seed=28, **c) == want
     # run-to-run determinism (fixed slice order, no atomics)
     W = synthetic.normal((N, K), torch.bfloat16, seed=1, std=0.05).to(DEV)
@@ -191,6 +191,9 @@ def test_matmul_splitk_path(case, monkeypatch):
     dict(M=40, N=11008, K=4096, dt=torch.bfloat16, cs=True, want="mfma_small_splitk"),           # 64-row form (MF = 4), wide layer
     dict(M=64, N=4096, K=4096, dt=torch.bfloat16, want="mfma_small_splitk"),                     # 64-row form, full tile
     dict(M=256, N=1024, K=2048, dt=torch.float16, bias=False, want="mfma_small_splitk"),         # two full m-tiles, 8-step slices
+    dict(M=64, N=4096, K=4096, dt=torch.bfloat16, bs=128, cs=True, want="mfma_small_splitk"),    # blocksize 128, double-quantised absmax
+    dict(M=150, N=520, K=1024, dt=torch.float16, bs=32, qt="fp4", want="mfma_small_splitk"),     # blocksize 32: one block per lane chunk
+    dict(M=100, N=512, K=4096, dt=torch.bfloat16, bs=2048, want="mfma_small_splitk"),            # blocksize 2048: a block spans 8 steps
     dict(M=384, N=11008, K=4096, dt=torch.bfloat16, cd=torch.float32, want="mfma_mid"),          # 516 tiles: no split, f32 output
     dict(M=300, N=8192, K=256, dt=torch.float16, want="mfma_mid"),                               # 4 k-steps, no split (384 tiles), wide layer
     dict(M=65, N=64, K=256, dt=torch.bfloat16, bias=False, want="mfma_mid"),                     # one tile, K too short to split
