@@ -293,7 +293,9 @@ int64_t mbnb_linear_int8_workspace_bytes(int64_t M, int64_t N, int64_t K) {
     const int64_t s = matmul4_splitk_slices(M, N, K);
     const int64_t a = s > 1 ? s * ((M + 127) / 128) * ((N + 127) / 128) * 65536 : 0;   // slices x tiles x 128 x 128 f32
     const int64_t c = gemm_dense_workspace_bytes(M, N, K, K);   // large M: the dequantised weight (+ split-K partials)
-    return a > c ? a : c;
+    const int64_t d = gemm_small_workspace_bytes(M, N, K, K);   // 32 < M <= 256: slices x M x N f32 (gemm_small8.h)
+    const int64_t ac = a > c ? a : c;
+    return ac > d ? ac : d;
 }
 
 int mbnb_gemm_dense(const void *A, const void *W, int dtype, const void *bias, int out_dtype, void *out, int64_t M, int64_t N,

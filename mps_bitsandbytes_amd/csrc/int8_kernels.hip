@@ -675,6 +675,9 @@ __global__ __launch_bounds__(1024) void k_skinny8(const T *__restrict__ X, const
 
 int64_t matmul4_splitk_slices(int64_t M, int64_t N, int64_t K);
 
+template <typename T, int WF>
+int launch_gemm_small8(const T *, const uint8_t *, const float *, const T *, T *, int64_t, int64_t, int64_t, float *, int64_t, hipStream_t);
+
 template <typename T, int WF = W8_INT8>
 static int launch_linear_int8(const void *X, int64_t M, int64_t K, const int8_t *W, const float *scales, int64_t N,
                               const void *bias, void *out, float *ws, int64_t ws_bytes, hipStream_t st) {
@@ -682,6 +685,11 @@ static int launch_linear_int8(const void *X, int64_t M, int64_t K, const int8_t 
     const T *b = static_cast<const T *>(bias);
     T *o = static_cast<T *>(out);
     if constexpr (sizeof(T) == 2) {
+        if (M > 32 && M <= 256) {
+            // 32 < M <= 256: weight operand decoded registers -> registers (gemm_small8.h); 1 = does not apply
+            const int rc = launch_gemm_small8<T, WF>(x, reinterpret_cast<const uint8_t *>(W), scales, b, o, M, N, K, ws, ws_bytes, st);
+            if (rc != 1) return rc;
+        }
         if (M >= 1 && M <= 64 && (K % 128 == 0) && (((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(W)) & 15) == 0)) {
             const unsigned grid = (unsigned)((N + 15) / 16);
 #define MBNB_SKINNY8(MT)                                                                                            \

@@ -642,7 +642,7 @@ def linear_int8(input: Tensor, weight_int8: Tensor, weight_scales: Tensor, bias:
     s = weight_scales.to(device=x.device, dtype=torch.float32).contiguous()
     b = None if bias is None else bias.to(device=x.device, dtype=dtype).contiguous()
     out = torch.empty(M, N, dtype=dtype, device=x.device)
-    ws_bytes = int((_native.lib().mbnb_linear_int8_workspace_bytes if DECODE_ONCE else _native.lib().mbnb_matmul_4bit_splitk_workspace_bytes)(M, N, K)) if M > 64 else 0   # split-K for mid-sized M
+    ws_bytes = int((_native.lib().mbnb_linear_int8_workspace_bytes if DECODE_ONCE else _native.lib().mbnb_matmul_4bit_splitk_workspace_bytes)(M, N, K)) if M > 16 else 0   # split-K for mid-sized M
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes > 0 else None
     with torch.cuda.device(x.device):
         check(_native.lib().mbnb_linear_int8_ws(ptr(x), dcode, M, K, ptr(w), ptr(s), N, ptr(b), ptr(out), ptr(ws), ws_bytes,
@@ -705,7 +705,7 @@ def matmul_fp8_e4m3(input: Tensor, weight: Tensor, weight_scales: Tensor, bias: 
     s = weight_scales.to(device=x2.device, dtype=torch.float32).contiguous()
     b = None if bias is None else bias.to(device=x2.device, dtype=dtype).contiguous()
     out = torch.empty(M, N, dtype=dtype, device=x2.device)
-    ws_bytes = int((_native.lib().mbnb_linear_int8_workspace_bytes if DECODE_ONCE else _native.lib().mbnb_matmul_4bit_splitk_workspace_bytes)(M, N, K)) if M > 64 else 0
+    ws_bytes = int((_native.lib().mbnb_linear_int8_workspace_bytes if DECODE_ONCE else _native.lib().mbnb_matmul_4bit_splitk_workspace_bytes)(M, N, K)) if M > 16 else 0
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x2.device) if ws_bytes > 0 else None
     with torch.cuda.device(x2.device):
         check(_native.lib().mbnb_linear_fp8(ptr(x2), dcode, M, K, ptr(w), ptr(s), N, ptr(b), ptr(out), ptr(ws), ws_bytes,

@@ -208,6 +208,7 @@ def test_linear_fp8_golden(g7):
 
 @pytest.mark.parametrize("M,N,K,dt,kern", [(1, 4096, 4096, torch.bfloat16, "fp8a16_skinny"), (33, 1000, 384, torch.float16, "fp8a16_skinny"),
                                             (300, 1000, 1024, torch.float16, "fp8a16_mfma128_splitk"), (200, 384, 80, torch.bfloat16, "fp8a16_mfma128"),
+                                            (150, 1000, 1024, torch.bfloat16, "fp8a16_small_splitk"), (48, 4096, 512, torch.float16, "fp8a16_small"),
                                             (2560, 2560, 256, torch.bfloat16, "fp8a16_dequant+dense"), (3, 50, 20, torch.float16, "fp8a16_generic")])
 def test_linear_fp8_kernels_vs_oracle(M, N, K, dt, kern):
     W = synthetic.normal((N, K), dt, seed=941, std=0.05)

@@ -661,9 +661,9 @@ def test_quantize_model_replaces_linears_and_matches_layerwise_oracle():
 
 @pytest.mark.parametrize("M,N,K,dt,bias", [(1, 4096, 4096, torch.bfloat16, False), (7, 1000, 384, torch.float16, True),
                                             (16, 11008, 4096, torch.bfloat16, True), (33, 300, 256, torch.float16, False),
-                                            (64, 4096, 1024, torch.bfloat16, True)])
+                                            (32, 4096, 1024, torch.bfloat16, True)])
 def test_linear_int8_skinny_path(M, N, K, dt, bias):
-    """Linear8bit.forward for 1 <= M <= 64: the int8 weight-streaming MFMA kernel (k_skinny8) vs the oracle."""
+    """Linear8bit.forward for 1 <= M <= 32 (<= 64 when K % 256 != 0): the int8 weight-streaming MFMA kernel (k_skinny8) vs the oracle."""
     W = synthetic.normal((N, K), dt, seed=61, std=0.05)
     q, s = oracle.quantize_rowwise(W)
     x = synthetic.normal((M, K), dt, seed=62)
@@ -674,16 +674,21 @@ def test_linear_int8_skinny_path(M, N, K, dt, bias):
     assert rel_fro(y, ref) <= TOL[dt]
 
 
-@pytest.mark.parametrize("M,N,K,dt,bias", [(128, 4096, 4096, torch.bfloat16, True), (300, 1000, 1024, torch.float16, False),
-                                            (240, 2048, 2048, torch.bfloat16, True)])
-def test_linear_int8_splitk_path(M, N, K, dt, bias):
-    """Linear8bit.forward for mid-sized M: 128 x 128 tiles, K split over a workspace (mbnb_linear_int8_ws)."""
+@pytest.mark.parametrize("M,N,K,dt,bias,kern", [(128, 4096, 4096, torch.bfloat16, True, "w8a16_small_splitk"),
+                                                 (300, 1000, 1024, torch.float16, False, "w8a16_mfma128_splitk"),
+                                                 (240, 2048, 2048, torch.bfloat16, True, "w8a16_small_splitk"),
+                                                 (64, 4096, 1024, torch.float16, True, "w8a16_small"),
+                                                 (40, 1000, 512, torch.bfloat16, False, "w8a16_small"),
+                                                 (200, 520, 448, torch.float16, True, "w8a16_mfma128")])
+def test_linear_int8_splitk_path(M, N, K, dt, bias, kern):
+    """Linear8bit.forward for mid-sized M: 32 < M <= 256 with K % 256 == 0 -> k_gemm_small8 (weight operand decoded registers to
+    registers, gemm_small8.h); otherwise 128 x 128 tiles; K split over a workspace (mbnb_linear_int8_ws)."""
     W = synthetic.normal((N, K), dt, seed=71, std=0.05)
     q, s = oracle.quantize_rowwise(W)
     x = synthetic.normal((M, K), dt, seed=72)
     b = synthetic.normal((N,), dt, seed=73) if bias else None
     y = bnb.linear_int8(x.to(DEV), q.to(DEV), s.to(DEV), None if b is None else b.to(DEV))
-    assert _native.last_kernel() == "w8a16_mfma128_splitk"
+    assert _native.last_kernel() == kern
     rows = torch.arange(0, M, max(1, M // 64))[:64]
     ref = oracle.linear_int8(x[rows], q, s, b)
     assert rel_fro(y.cpu()[rows], ref) <= TOL[dt]
