@@ -7,7 +7,7 @@ namespace mbnb {
 bool gemm_small_shape(int64_t M, int64_t N, int64_t K, int64_t K_weight) {
     // from 33 rows (17 for layers of more than 16 Mi weights) the weight-streaming skinny kernel loses: 64 x 4096 x 4096 12.8 us
     // here, 18.5 there; 32 x 4096 x 4096 11.8 vs 11.7; 32 x 11008 x 4096 21.7 vs 31.0 (tools/exp/small_check.py)
-    return (M > 32 || (M > 16 && N * K > ((int64_t)1 << 24))) && M <= 256 && K % 256 == 0 && K >= 512 && K <= 16 * 2048 && K_weight % 256 == 0 && N >= 64 &&
+    return (M > 32 || (M > 16 && N * K > ((int64_t)1 << 24))) && M <= 384 && K % 256 == 0 && K >= 512 && K <= 16 * 2048 && K_weight % 256 == 0 && N >= 64 &&
            256 * K * 2 < ((int64_t)1 << 31);
 }
 // Plan = (NF: n-fragments per wave -> 64 NF weight rows per workgroup; K slices).  The kernel is bound by what a workgroup takes

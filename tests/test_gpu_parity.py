@@ -194,7 +194,7 @@ def test_matmul_splitk_path(case, monkeypatch):
     dict(M=64, N=4096, K=4096, dt=torch.bfloat16, bs=128, cs=True, want="mfma_small_splitk"),    # blocksize 128, double-quantised absmax
     dict(M=150, N=520, K=1024, dt=torch.float16, bs=32, qt="fp4", want="mfma_small_splitk"),     # blocksize 32: one block per lane chunk
     dict(M=100, N=512, K=4096, dt=torch.bfloat16, bs=2048, want="mfma_small_splitk"),            # blocksize 2048: a block spans 8 steps
-    dict(M=384, N=11008, K=4096, dt=torch.bfloat16, cd=torch.float32, want="mfma_mid"),          # 516 tiles: no split, f32 output
+    dict(M=384, N=11008, K=4096, dt=torch.bfloat16, cd=torch.float32, want="mfma_small_splitk"), # three m-tiles, f32 output
     dict(M=300, N=8192, K=256, dt=torch.float16, want="mfma_mid"),                               # 4 k-steps, no split (384 tiles), wide layer
     dict(M=65, N=64, K=256, dt=torch.bfloat16, bias=False, want="mfma_mid"),                     # one tile, K too short to split
 ])
@@ -360,8 +360,8 @@ def test_matmul_row_independence_and_linearity_full_size():
     Yh = bnb.matmul_4bit(X * 0.5, packed, st)
     big = Y.abs() > 1e-2
     assert torch.equal((Yh * 2)[big], Y[big])
-    # the same rows through the other kernels: GEMV (1 row), skinny MFMA (4 and 24 rows), split-K (300 rows)
-    for rows_n, kern in ((1, "gemv"), (4, "skinny_mfma16"), (24, "skinny_mfma16"), (150, "mfma_small_splitk"), (300, "mfma128_splitk")):
+    # the same rows through the other kernels: GEMV (1 row), skinny MFMA (4, 24 rows), k_gemm_small (150, 300), decode once + split-K (500)
+    for rows_n, kern in ((1, "gemv"), (4, "skinny_mfma16"), (24, "skinny_mfma16"), (150, "mfma_small_splitk"), (300, "mfma_small_splitk"), (500, "dequant+dense_splitk")):
         yg = bnb.matmul_4bit(X[:rows_n], packed, st)
         assert _native.last_kernel() == kern
         assert rel_fro(yg, Y[:rows_n]) <= TOL[torch.float16]

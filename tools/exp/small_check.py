@@ -43,7 +43,7 @@ def graph_us(fn, n=20, reps=7):
     return statistics.median(ts)
 
 
-shapes = [(17, 4096, 4096), (24, 4096, 4096), (32, 4096, 4096), (32, 11008, 4096), (33, 4096, 4096), (48, 4096, 4096), (64, 4096, 4096), (64, 11008, 4096), (72, 4096, 4096), (96, 4096, 4096), (128, 4096, 4096), (192, 4096, 4096), (256, 4096, 4096), (128, 11008, 4096), (256, 11008, 4096),
+shapes = [(280, 4096, 4096), (320, 4096, 4096), (360, 4096, 4096), (300, 2048, 8192), (17, 4096, 4096), (24, 4096, 4096), (32, 4096, 4096), (32, 11008, 4096), (33, 4096, 4096), (48, 4096, 4096), (64, 4096, 4096), (64, 11008, 4096), (72, 4096, 4096), (96, 4096, 4096), (128, 4096, 4096), (192, 4096, 4096), (256, 4096, 4096), (128, 11008, 4096), (256, 11008, 4096),
           (128, 4096, 11008), (100, 1024, 1024), (200, 4096, 1024)]
 for (M, N, K) in shapes:
     for dt, cs in ((torch.bfloat16, False), (torch.bfloat16, True)):
