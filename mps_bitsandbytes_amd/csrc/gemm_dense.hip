@@ -53,7 +53,8 @@ bool gemm_dense_shape(int64_t M, int64_t N, int64_t K, int64_t K_weight) {
     if (256 * (K > K_weight ? K : K_weight) * 2 >= ((int64_t)1 << 31)) return false;
     if (M * N * 4 >= ((int64_t)1 << 40)) return false;
     // from 256 rows and 1.5 M outputs up (sweep3: 384 x 4096 x 4096 35.5 us here, 43.2 fused; 256 x 4096 x 4096 stays fused, 28.4 vs 33.8)
-    return M >= 256 && M * N >= 1500000;
+    // (280-360 x 4096 x 4096: 34.4-34.7 us here against 36-39.5 for k_gemm_small with three m-tiles)
+    return (M >= 256 && M * N >= 1500000) || (M > 256 && M * N >= 1000000);
 }
 int64_t gemm_dense_wd_bytes(int64_t N, int64_t K_weight) { return (N * K_weight * 2 + 255) & ~(int64_t)255; }
 int64_t gemm_dense_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t K_weight) {

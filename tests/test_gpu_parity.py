@@ -360,8 +360,8 @@ def test_matmul_row_independence_and_linearity_full_size():
     Yh = bnb.matmul_4bit(X * 0.5, packed, st)
     big = Y.abs() > 1e-2
     assert torch.equal((Yh * 2)[big], Y[big])
-    # the same rows through the other kernels: GEMV (1 row), skinny MFMA (4, 24 rows), k_gemm_small (150, 300), decode once + split-K (500)
-    for rows_n, kern in ((1, "gemv"), (4, "skinny_mfma16"), (24, "skinny_mfma16"), (150, "mfma_small_splitk"), (300, "mfma_small_splitk"), (500, "dequant+dense_splitk")):
+    # the same rows through the other kernels: GEMV (1 row), skinny MFMA (4, 24 rows), k_gemm_small (150, 240), decode once + split-K (500)
+    for rows_n, kern in ((1, "gemv"), (4, "skinny_mfma16"), (24, "skinny_mfma16"), (150, "mfma_small_splitk"), (240, "mfma_small_splitk"), (500, "dequant+dense_splitk")):
         yg = bnb.matmul_4bit(X[:rows_n], packed, st)
         assert _native.last_kernel() == kern
         assert rel_fro(yg, Y[:rows_n]) <= TOL[torch.float16]
