@@ -715,6 +715,27 @@ def test_matmul_4bit_randomized_dispatch_sweep():
     assert {"gemv", "skinny_mfma16", "mfma128", "mfma128_splitk", "generic"} <= set(seen), seen
 
 
+def test_matmul_4bit_randomized_sweep_round2_kernels():
+    """48 pseudo-random shapes in the range of the round-2 kernels -- k_gemm_small (33 .. 384 rows), decode once + k_gemm_dense
+    (both tile shapes, with and without split-K) -- with ragged M and N, every blocksize >= 32, both code tables, nested absmax,
+    bias and output casts, against the oracle."""
+    rng = np.random.default_rng(20261006)
+    seen = {}
+    for case in range(48):
+        M = int(rng.choice([33, 40, 64, 65, 100, 128, 129, 200, 256, 257, 300, 384, 385, 500, 777, 1024, 1500, 2049]))
+        N = int(rng.choice([64, 65, 100, 257, 520, 1000, 1024, 2600, 4096, 5001]))
+        K = int(rng.choice([512, 768, 1024, 1280, 2048, 4096]))
+        bs = int(rng.choice([32, 64, 64, 64, 128, 1024]))
+        dt = [torch.float16, torch.bfloat16][int(rng.integers(0, 2))]
+        qt = "nf4" if rng.random() < 0.7 else "fp4"
+        cs = bool(rng.random() < 0.35)
+        bias = bool(rng.random() < 0.5)
+        cd = None if rng.random() < 0.7 else [torch.float16, torch.bfloat16, torch.float32][int(rng.integers(0, 3))]
+        kern = _oracle_vs_gpu_matmul(M, N, K, dt, qt=qt, bs=bs, cs=cs, bias=bias, cd=cd, seed=5000 + case)
+        seen[kern] = seen.get(kern, 0) + 1
+    assert {"mfma_small_splitk", "dequant+dense", "dequant+dense_splitk"} <= set(seen), seen
+
+
 def test_linear_int8_randomized_dispatch_sweep():
     """60 pseudo-random Linear8bit.forward shapes against the oracle (skinny, 128^2, split-K and generic paths)."""
     rng = np.random.default_rng(20261005)
