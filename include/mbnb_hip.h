@@ -152,7 +152,8 @@ int mbnb_double_quant(const void *A, int dtype, int64_t rows, int64_t cols, int8
  * weights) -> weight-streaming skinny MFMA kernel; shapes with >= 96 output tiles of 256 x 256
  * -> the 256 x 256 LDS-DMA MFMA kernel with the dequant fused into the weight-tile producer;
  * in between -> 128 x 128 MFMA tiles (split over K when mbnb_matmul_4bit_ws gets a workspace);
- * fp32 weights, blocksize < 32, K % 8 != 0 -> generic kernel.
+ * fp32 weights: with a workspace (mbnb_matmul_4bit_workspace_bytes_dt) dequantise once + f32 MFMA GEMM, else generic;
+ * blocksize < 32, K % 8 != 0 -> generic kernel.
  * ------------------------------------------------------------------------- */
 int mbnb_matmul_4bit(const void *A, int64_t M, int64_t K, const uint8_t *packed,
                      const mbnb_absmax *absmax, int64_t N, int64_t K_weight, int blocksize,
@@ -174,6 +175,10 @@ int64_t mbnb_matmul_4bit_workspace_bytes(int64_t M, int64_t N, int64_t K);
  * (functional.py:753-767, "used for M > 512": dequantize_4bit, then F.linear).  A workspace shorter than the query costs the fast path, never
  * the result. */
 int64_t mbnb_matmul_4bit_workspace_bytes_kw(int64_t M, int64_t N, int64_t K, int64_t K_weight);
+/* The query by weight dtype.  MBNB_F16 / MBNB_BF16: the one above.  MBNB_F32 (QuantState.dtype of a default nn.Linear; the
+ * reference multiplies in f32, functional.py:756-773): from 5 rows up, K % 4 == 0, the weight dequantised once as f32
+ * [N, K_weight] (N x K_weight x 4 bytes) for a dense f32 MFMA GEMM (csrc/gemm_f32.hip) instead of the generic kernel. */
+int64_t mbnb_matmul_4bit_workspace_bytes_dt(int64_t M, int64_t N, int64_t K, int64_t K_weight, int w_dtype);
 /* The split-K share of that query alone: a caller that cannot spare N x K_weight x 2 bytes passes a workspace of this size
  * and keeps the fused dequant + MFMA kernels at every M (0 = no split needed). */
 int64_t mbnb_matmul_4bit_splitk_workspace_bytes(int64_t M, int64_t N, int64_t K);

@@ -55,6 +55,7 @@ _SIGNATURES = {
                                  c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "mbnb_matmul_4bit_workspace_bytes": (c_int64, [c_int64, c_int64, c_int64]),
     "mbnb_matmul_4bit_workspace_bytes_kw": (c_int64, [c_int64, c_int64, c_int64, c_int64]),
+    "mbnb_matmul_4bit_workspace_bytes_dt": (c_int64, [c_int64, c_int64, c_int64, c_int64, c_int]),
     "mbnb_matmul_4bit_splitk_workspace_bytes": (c_int64, [c_int64, c_int64, c_int64]),
     "mbnb_linear_int8_workspace_bytes": (c_int64, [c_int64, c_int64, c_int64]),
     "mbnb_gemm_dense": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p,

@@ -73,6 +73,7 @@ int64_t matmul4_splitk_slices(int64_t, int64_t, int64_t);
 int probe_mfma_dispatch(int, int, float *, hipStream_t);
 int64_t gemm_mid_workspace_bytes(int64_t, int64_t, int64_t);
 int64_t gemm_small_workspace_bytes(int64_t, int64_t, int64_t, int64_t);
+int64_t gemm_f32_workspace_bytes(int64_t, int64_t, int64_t, int64_t);
 int64_t gemm_dense_workspace_bytes(int64_t, int64_t, int64_t, int64_t);
 int gemm_dense_direct(const void *, const void *, int, const void *, int, void *, int64_t, int64_t, int64_t, int64_t, float *, int64_t, int,
                       hipStream_t);
@@ -282,6 +283,12 @@ int64_t mbnb_matmul_4bit_workspace_bytes_kw(int64_t M, int64_t N, int64_t K, int
     const int64_t ab = mbnb_matmul_4bit_splitk_workspace_bytes(M, N, K);
     const int64_t c = gemm_dense_workspace_bytes(M, N, K, K_weight);   // the dequantised weight (+ split-K partials): large M
     return ab > c ? ab : c;
+}
+
+int64_t mbnb_matmul_4bit_workspace_bytes_dt(int64_t M, int64_t N, int64_t K, int64_t K_weight, int w_dtype) {
+    if (w_dtype != MBNB_F32) return mbnb_matmul_4bit_workspace_bytes_kw(M, N, K, K_weight);
+    if (M <= 0 || N <= 0 || K <= 0 || K_weight < K) return 0;
+    return gemm_f32_workspace_bytes(M, N, K, K_weight);
 }
 
 int64_t mbnb_matmul_4bit_workspace_bytes(int64_t M, int64_t N, int64_t K) {

@@ -34,6 +34,7 @@ bool gemm_small_shape(int64_t M, int64_t N, int64_t K, int64_t K_weight);
 template <typename T, typename OutT, bool NESTED>
 int launch_gemm_small(const T *, const uint8_t *, const AbsmaxView &, const T *, OutT *, int64_t, int64_t, int64_t, int64_t, int, int, float *,
                       int64_t, hipStream_t);
+int matmul_4bit_f32_path(const void *, int64_t, int64_t, const uint8_t *, const AbsmaxView &, int64_t, int64_t, int, int, const void *, int, void *, void *, int64_t, hipStream_t);
 int matmul_4bit_dense_path(const void *, int64_t, int64_t, const uint8_t *, const AbsmaxView &, int64_t, int64_t, int, int, int, const void *,
                            int, void *, void *, int64_t, hipStream_t);
 
@@ -467,6 +468,10 @@ int matmul_4bit_dispatch(const void *A, int64_t M, int64_t K, const uint8_t *pac
         const int rc = matmul_4bit_dense_path(A, M, K, packed, am, N, K_weight, blocksize, qt, w_dtype, bias, out_dtype, out, workspace,
                                               ws_bytes, st);
         if (rc != 1) return rc;
+        if (w_dtype == MBNB_F32) {   // f32 weights: decode once + f32 MFMA GEMM (gemm_f32.hip)
+            const int rf = matmul_4bit_f32_path(A, M, K, packed, am, N, K_weight, blocksize, qt, bias, out_dtype, out, workspace, ws_bytes, st);
+            if (rf != 1) return rf;
+        }
     }
     float *ws = static_cast<float *>(workspace);
     switch (w_dtype) {

@@ -542,9 +542,10 @@ def matmul_4bit(
         raise ValueError(f"packed weight has {packed.numel()} bytes, expected {N * K_weight // 2}")
     _check_absmax_count(quant_state.absmax, N, K_weight, blocksize, "matmul_4bit")
 
-    if M * N * K >= (1 << 27) and (w_dtype == torch.float32 or blocksize < 32 or K % 8 != 0):
-        # the MFMA / weight-streaming kernels need a 16-bit QuantState.dtype, blocksize >= 32 and K % 8 == 0; anything else
-        # runs on the generic one-wave-per-output-column kernel, orders of magnitude slower at this size
+    if M * N * K >= (1 << 27) and ((w_dtype == torch.float32 and (K % 4 != 0 or not DECODE_ONCE)) or
+                                   (w_dtype != torch.float32 and (blocksize < 32 or K % 8 != 0))):
+        # the 16-bit MFMA / weight-streaming kernels need blocksize >= 32 and K % 8 == 0, the f32 decode-once path K % 4 == 0;
+        # anything else runs on the generic one-wave-per-output-column kernel, orders of magnitude slower at this size
         _warn_once("matmul_4bit.generic",
                    f"matmul_4bit: weight dtype {w_dtype}, blocksize {blocksize}, K {K} takes the generic (non-MFMA) kernel; "
                    f"quantize a float16 / bfloat16 weight with blocksize >= 32 and K % 8 == 0 for the fast paths "
@@ -558,7 +559,7 @@ def matmul_4bit(
     # runs a dense MFMA GEMM instead of re-decoding every weight tile per 256 rows.  torch's caching allocator makes the
     # allocation a pointer bump; the memory goes back to the pool on return.
     if DECODE_ONCE:
-        ws_bytes = int(_native.lib().mbnb_matmul_4bit_workspace_bytes_kw(M, N, K, K_weight))
+        ws_bytes = int(_native.lib().mbnb_matmul_4bit_workspace_bytes_dt(M, N, K, K_weight, w_code))
     else:
         ws_bytes = int(_native.lib().mbnb_matmul_4bit_splitk_workspace_bytes(M, N, K))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=A.device) if ws_bytes > 0 else None

@@ -278,6 +278,40 @@ def test_matmul_decode_once_path(case, monkeypatch):
         assert rel_fro(y, y_fused.cpu()) <= TOL[dt]
 
 
+@pytest.mark.parametrize("case", [
+    dict(M=40, N=512, K=256, want="dequant+dense_f32"),        # 64 x 64 tiles, ragged M, K too short to split
+    dict(M=5, N=4096, K=4096, want="dequant+dense_f32_splitk"),    # the first row count of the path: 64 tiles x 16 slices
+    dict(M=300, N=1000, K=1028, cs=True, want="dequant+dense_f32_splitk"),   # ragged everything, K_weight = 1088 > K, nested absmax, short last slice
+    dict(M=131, N=96, K=336, qt="fp4", bs=16, cd=torch.float16),   # small blocksize, k tail (336 = 21 x 16), f16 output
+    dict(M=2048, N=3072, K=512, bs=128, cd=torch.bfloat16, want="dequant+dense_f32"),   # 128 x 128 tiles (384 of them), bf16 output
+    dict(M=2500, N=2100, K=260, bias=False, want="dequant+dense_f32"),   # 128 x 128 tiles, ragged, short last k step, no bias
+    dict(M=1000, N=1000, K=1024, want="dequant+dense_f32_splitk"),        # 64 x 64 tiles, 4 slices
+])
+def test_matmul_f32_weight_decode_once_path(case, monkeypatch):
+    """QuantState.dtype float32 (the weight of a default nn.Linear; functional.py:756-773 multiplies in f32): from 5 rows up
+    dequantize_4bit (f32) into the scratch + k_gemm_f32 on v_mfma_f32_32x32x2_f32 (gemm_f32.hip).  Parity vs the oracle at
+    the f32 tolerance, run-to-run determinism, and agreement with the generic kernel it replaces."""
+    c = dict(case)
+    M, N, K, want = c.pop("M"), c.pop("N"), c.pop("K"), c.pop("want", None)
+    kern = _oracle_vs_gpu_matmul(M, N, K, torch.float32, seed=61, **c)
+    assert kern in ("dequant+dense_f32", "dequant+dense_f32_splitk") and (want is None or kern == want), kern
+    W = synthetic.normal((N, K), torch.float32, seed=61)
+    X = synthetic.normal((M, K), torch.float32, seed=62).to(DEV)
+    packed, st = bnb.quantize_4bit(W.to(DEV), blocksize=c.get("bs", 64), quant_type=c.get("qt", "nf4"), compress_statistics=c.get("cs", False))
+    y = bnb.matmul_4bit(X, packed, st, None, c.get("cd"))
+    assert _native.last_kernel() == kern
+    assert torch.equal(y, bnb.matmul_4bit(X, packed, st, None, c.get("cd")))
+    monkeypatch.setattr(bnb.functional, "DECODE_ONCE", False)
+    y_gen = bnb.matmul_4bit(X, packed, st, None, c.get("cd"))
+    assert _native.last_kernel() == "generic"
+    assert rel_fro(y, y_gen.cpu()) <= max(TOL[torch.float32], TOL[y.dtype])
+
+
+def test_matmul_f32_weight_small_or_unaligned_stays_generic():
+    assert _oracle_vs_gpu_matmul(4, 512, 1024, torch.float32, seed=63) == "generic"      # M <= 4: the packed weight streamed once per row
+    assert _oracle_vs_gpu_matmul(64, 256, 130, torch.float32, seed=64) == "generic"      # K % 4 != 0
+
+
 @pytest.mark.parametrize("qt", ["nf4", "fp4"])
 @pytest.mark.parametrize("cs", [False, True])
 @pytest.mark.parametrize("bs", [32, 64, 128, 256])
