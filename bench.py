@@ -765,6 +765,27 @@ def main():
                     "dtod_copy_gbs_read_plus_write": round(2.0 * (1 << 30) / (copy_ms * 1e-3) / 1e9, 0)}
             except Exception as e:  # context only: never fails the bench
                 out["roofline"]["empirical"] = {"error": str(e)[:200]}
+    if rank == 0 and wl == "int8_4096" and not args.no_empirical:
+        # what the int8 matrix pipe sustains on THIS box (bare v_mfma_i32_32x32x32_i8 loop, one wave per SIMD)
+        try:
+            sink = torch.zeros(1, dtype=torch.float32, device=dev)
+            stp = torch.cuda.current_stream().cuda_stream
+            lib = _native.lib()
+            lib.mbnb_probe_mfma(1, 2000, sink.data_ptr(), stp)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            n_mfma = 0
+            for _ in range(10):
+                n_mfma += int(lib.mbnb_probe_mfma(1, 20000, sink.data_ptr(), stp))
+            e1.record()
+            e1.synchronize()
+            if n_mfma > 0:
+                out["roofline"]["empirical"] = {
+                    "bare_mfma_loop_i8_tops": round(n_mfma * 65536.0 / (e0.elapsed_time(e1) * 1e-3) / 1e12, 1),   # 2*32*32*32 per MFMA
+                    "bare_mfma_note": "v_mfma_i32_32x32x32_i8 back to back on every SIMD, nothing else: the sustained int8 matrix rate at the clock the chip holds under that load"}
+        except Exception as e:  # context only
+            out["roofline"]["empirical"] = {"error": str(e)[:200]}
     if rank == 0 and not args.no_cpu_baseline and world == 1 and wl in ("nf4_m4096", "nf4dq_ffn"):
         out["cpu_baseline"] = cpu_baseline(args, M, N, K, 64, compress, dt)
     if rank == 0 and not args.no_cpu_baseline and world == 1 and wl == "nf4_m1":

@@ -38,7 +38,8 @@ __global__ __launch_bounds__(256) void k_probe_mfma(int iters, float *sink, uint
         int si = 0;
 #pragma unroll
         for (int e = 0; e < 16; e++) si += d0[e] ^ d1[e] ^ d2[e] ^ d3[e];
-        s = (float)si;
+        // an integer test: `(float)si == 123.456f` can never hold (an integer has no fraction) and the whole loop was folded away
+        if (si == 0x12345679) sink[0] = 1.0f;
     }
     if (s == 123.456f) sink[0] = s;
 }

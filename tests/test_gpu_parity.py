@@ -490,7 +490,7 @@ def test_g5_matmul_int8_and_linear8bit(golden):
 
 
 @pytest.mark.parametrize("shape", [(256, 256, 256), (200, 136, 320), (2500, 2600, 384), (2500, 2608, 384), (2560, 2560, 128),
-                                   (2500, 2624, 384), (4096, 4096, 4096)])
+                                   (2500, 2624, 384), (2560, 2560, 384), (4096, 4096, 4096)])
 def test_matmul_int8_mfma_exact_vs_integer_reference(shape):
     """BASELINE configs[3] (4096^3) and smaller: the int8 MFMA contraction is exact in int32, so the
     f32 result must match torch's integer matmul formula to f32 rounding.  N % 16 == 0 and K % 128 == 0 with >= 96 tiles
