@@ -176,7 +176,8 @@ int64_t mbnb_matmul_4bit_workspace_bytes(int64_t M, int64_t N, int64_t K);
  * the result. */
 int64_t mbnb_matmul_4bit_workspace_bytes_kw(int64_t M, int64_t N, int64_t K, int64_t K_weight);
 /* The query by weight dtype.  MBNB_F16 / MBNB_BF16: the one above.  MBNB_F32 (QuantState.dtype of a default nn.Linear; the
- * reference multiplies in f32, functional.py:756-773): from 5 rows up, K % 4 == 0, the weight dequantised once as f32
+ * reference multiplies in f32, functional.py:756-773): where it beats the generic kernel (from 17 rows at 4096^2, ~100 rows
+ * at 1024^2; K % 4 == 0), the weight dequantised once as f32
  * [N, K_weight] (N x K_weight x 4 bytes) for a dense f32 MFMA GEMM (csrc/gemm_f32.hip) instead of the generic kernel. */
 int64_t mbnb_matmul_4bit_workspace_bytes_dt(int64_t M, int64_t N, int64_t K, int64_t K_weight, int w_dtype);
 /* The split-K share of that query alone: a caller that cannot spare N x K_weight x 2 bytes passes a workspace of this size

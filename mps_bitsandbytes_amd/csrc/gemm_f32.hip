@@ -125,10 +125,13 @@ __global__ __launch_bounds__(256) void k_gemm_f32(const float *__restrict__ X, c
     }
 }
 
-// From five rows up (below that the generic kernel streams the packed weight once per row and is the cheaper form), at
-// sizes where two launches pay.  K % 4 == 0: rows of X are read 16 bytes at a time.
+// Where two (three with split-K) launches beat the generic kernel, which streams the packed weight once per 8 rows
+// (tools/exp/f32_crossover.py, r = N K / 4096^2: generic ~ 4 + ceil(M / 8) (0.15 + 17 r) us, this path ~ 18 + 31 r us at small
+// M): from 17 rows at 4096^2, from ~100 rows at 1024^2.  K % 4 == 0: rows of X are read 16 bytes at a time.
 bool gemm_f32_shape(int64_t M, int64_t N, int64_t K, int64_t K_weight) {
-    return M >= 5 && N >= 32 && K >= 16 && K % 4 == 0 && K_weight % 4 == 0 && M * N * K >= ((int64_t)1 << 20);
+    if (M < 5 || N < 32 || K < 16 || K % 4 != 0 || K_weight % 4 != 0) return false;
+    const double r = (double)N * (double)K / 16777216.0;
+    return (double)((M + 7) / 8) * (0.15 + 17.0 * r) + 4.0 > 18.0 + 31.0 * r;
 }
 
 // 128 x 128 tiles from one per CU up (two fit a CU: 72 KiB of LDS each; 1024 x 4096^2: 336 us against 352 us on 64 x 64

@@ -41,11 +41,14 @@ int matmul_4bit_dense_path(const void *, int64_t, int64_t, const uint8_t *, cons
 // =====================================================================================
 // generic kernel: wave per (n, m-chunk of MT rows); lanes stride over k in steps of 8
 // =====================================================================================
+// flags: bit 0 = a lane's 8 weights are one aligned dword of `packed` and share one absmax (K_weight % 8 == 0, blocksize >= 8,
+// packed 4-byte aligned); bit 1 = a lane's 8 activations of a row are 16-byte loads (X 16-byte aligned, row pitch a multiple
+// of 16 bytes).  Same values, same fma order per lane with and without the flags: the results do not depend on them.
 template <typename T, typename OutT, int QT, bool NESTED, int MT>
 __global__ __launch_bounds__(256) void k_matmul4_generic(const T *__restrict__ X, const uint8_t *__restrict__ packed,
                                                         AbsmaxView am, const T *__restrict__ bias,
                                                         OutT *__restrict__ out, int64_t M, int64_t N, int64_t K,
-                                                        int64_t K_weight, int blocksize) {
+                                                        int64_t K_weight, int bs_shift, int flags) {
     __shared__ float lut[16];
     fill_code_lut<QT>(lut, threadIdx.x);
     __syncthreads();
@@ -53,30 +56,50 @@ __global__ __launch_bounds__(256) void k_matmul4_generic(const T *__restrict__ X
     const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t m0 = (int64_t)blockIdx.y * MT;
     if (n >= N) return;
-    const int64_t nblk = K_weight / blocksize;
+    const int64_t nblk = K_weight >> bs_shift;
+    const bool wfast = flags & 1, xvec = flags & 2;
     float acc[MT];
 #pragma unroll
     for (int i = 0; i < MT; i++) acc[i] = 0.0f;
     for (int64_t k0 = (int64_t)lane * 8; k0 < K; k0 += 512) {
         float w[8];
+        if (wfast) {
+            const int64_t flat = n * K_weight + k0;
+            const uint32_t pk = *reinterpret_cast<const uint32_t *>(packed + (flat >> 1));
+            const float a = load_absmax<NESTED>(am, n * nblk + (k0 >> bs_shift));
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const int64_t k = k0 + j;
-            if (k < K) {
-                const int64_t flat = n * K_weight + k;
-                const uint8_t b = packed[flat >> 1];
-                const int idx = (flat & 1) ? (b >> 4) : (b & 15);
-                const float v = lut[idx] * load_absmax<NESTED>(am, n * nblk + k / blocksize);
-                w[j] = to_f32(from_f32<T>(v));  // weight rounded to its dtype (functional.py:382)
-            } else w[j] = 0.0f;
+            for (int j = 0; j < 8; j++)
+                w[j] = (k0 + j < K) ? to_f32(from_f32<T>(lut[(pk >> (4 * j)) & 15] * a)) : 0.0f;   // weight rounded to its dtype (functional.py:382)
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int64_t k = k0 + j;
+                if (k < K) {
+                    const int64_t flat = n * K_weight + k;
+                    const uint8_t b = packed[flat >> 1];
+                    const int idx = (flat & 1) ? (b >> 4) : (b & 15);
+                    const float v = lut[idx] * load_absmax<NESTED>(am, n * nblk + (k >> bs_shift));
+                    w[j] = to_f32(from_f32<T>(v));
+                } else w[j] = 0.0f;
+            }
         }
 #pragma unroll
         for (int i = 0; i < MT; i++) {
             const int64_t m = m0 + i;
             if (m < M) {
+                if (xvec && k0 + 8 <= K) {
+                    __attribute__((aligned(16))) T xv[8];
+                    constexpr int NV = (int)sizeof(T) * 8 / 16;
 #pragma unroll
-                for (int j = 0; j < 8; j++)
-                    if (k0 + j < K) acc[i] = fmaf(to_f32(X[m * K + k0 + j]), w[j], acc[i]);
+                    for (int v = 0; v < NV; v++)
+                        reinterpret_cast<u32x4 *>(xv)[v] = reinterpret_cast<const u32x4 *>(X + m * K + k0)[v];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) acc[i] = fmaf(to_f32(xv[j]), w[j], acc[i]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; j++)
+                        if (k0 + j < K) acc[i] = fmaf(to_f32(X[m * K + k0 + j]), w[j], acc[i]);
+                }
             }
         }
     }
@@ -420,12 +443,18 @@ static int launch_matmul4(const void *A, int64_t M, int64_t K, const uint8_t *pa
     }
     {
         const unsigned gx = (unsigned)((N + 3) / 4);
-        if (M <= 4)
-            hipLaunchKernelGGL((k_matmul4_generic<T, OutT, QT, NESTED, 1>), dim3(gx, (unsigned)M), dim3(256), 0, st, x,
-                               packed, am, b, o, M, N, K, K_weight, blocksize);
+        const int bs_shift = ilog2(blocksize);
+        const int flags = ((K_weight % 8 == 0 && blocksize >= 8 && (reinterpret_cast<uintptr_t>(packed) & 3) == 0) ? 1 : 0) |
+                          (((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (K * (int64_t)sizeof(T)) % 16 == 0) ? 2 : 0);
+        if (M == 1)
+            hipLaunchKernelGGL((k_matmul4_generic<T, OutT, QT, NESTED, 1>), dim3(gx, 1), dim3(256), 0, st, x,
+                               packed, am, b, o, M, N, K, K_weight, bs_shift, flags);
+        else if (M <= 4)   // the packed weight once for all rows
+            hipLaunchKernelGGL((k_matmul4_generic<T, OutT, QT, NESTED, 4>), dim3(gx, 1), dim3(256), 0, st, x,
+                               packed, am, b, o, M, N, K, K_weight, bs_shift, flags);
         else
             hipLaunchKernelGGL((k_matmul4_generic<T, OutT, QT, NESTED, 8>), dim3(gx, (unsigned)((M + 7) / 8)),
-                               dim3(256), 0, st, x, packed, am, b, o, M, N, K, K_weight, blocksize);
+                               dim3(256), 0, st, x, packed, am, b, o, M, N, K, K_weight, bs_shift, flags);
         set_kernel_name("generic");
         return check_launch("matmul_4bit(generic)");
     }

@@ -279,17 +279,18 @@ def test_matmul_decode_once_path(case, monkeypatch):
 
 
 @pytest.mark.parametrize("case", [
-    dict(M=40, N=512, K=256, want="dequant+dense_f32"),        # 64 x 64 tiles, ragged M, K too short to split
-    dict(M=5, N=4096, K=4096, want="dequant+dense_f32_splitk"),    # the first row count of the path: 64 tiles x 16 slices
+    dict(M=600, N=512, K=224, want="dequant+dense_f32"),       # 64 x 64 tiles, ragged M, K too short to split
+    dict(M=17, N=4096, K=4096, want="dequant+dense_f32_splitk"),   # the first row count of the path at this size: 64 tiles x 16 slices
     dict(M=300, N=1000, K=1028, cs=True, want="dequant+dense_f32_splitk"),   # ragged everything, K_weight = 1088 > K, nested absmax, short last slice
-    dict(M=131, N=96, K=336, qt="fp4", bs=16, cd=torch.float16),   # small blocksize, k tail (336 = 21 x 16), f16 output
+    dict(M=1203, N=96, K=336, qt="fp4", bs=16, cd=torch.float16),  # small blocksize, k tail (336 = 10 x 32 + 16), f16 output
     dict(M=2048, N=3072, K=512, bs=128, cd=torch.bfloat16, want="dequant+dense_f32"),   # 128 x 128 tiles (384 of them), bf16 output
     dict(M=2500, N=2100, K=260, bias=False, want="dequant+dense_f32"),   # 128 x 128 tiles, ragged, short last k step, no bias
     dict(M=1000, N=1000, K=1024, want="dequant+dense_f32_splitk"),        # 64 x 64 tiles, 4 slices
 ])
 def test_matmul_f32_weight_decode_once_path(case, monkeypatch):
     """QuantState.dtype float32 (the weight of a default nn.Linear; functional.py:756-773 multiplies in f32): from 5 rows up
-    dequantize_4bit (f32) into the scratch + k_gemm_f32 on v_mfma_f32_32x32x2_f32 (gemm_f32.hip).  Parity vs the oracle at
+    dequantize_4bit (f32) into the scratch + k_gemm_f32 on v_mfma_f32_32x32x2_f32 (gemm_f32.hip) wherever that beats the generic
+    kernel (from 17 rows at 4096^2, ~100 rows at 1024^2).  Parity vs the oracle at
     the f32 tolerance, run-to-run determinism, and agreement with the generic kernel it replaces."""
     c = dict(case)
     M, N, K, want = c.pop("M"), c.pop("N"), c.pop("K"), c.pop("want", None)
@@ -308,7 +309,9 @@ def test_matmul_f32_weight_decode_once_path(case, monkeypatch):
 
 
 def test_matmul_f32_weight_small_or_unaligned_stays_generic():
-    assert _oracle_vs_gpu_matmul(4, 512, 1024, torch.float32, seed=63) == "generic"      # M <= 4: the packed weight streamed once per row
+    assert _oracle_vs_gpu_matmul(4, 512, 1024, torch.float32, seed=63) == "generic"      # M <= 4: the packed weight streamed once
+    assert _oracle_vs_gpu_matmul(16, 4096, 4096, torch.float32, seed=65) == "generic"    # two 8-row chunks: still cheaper than three launches
+    assert _oracle_vs_gpu_matmul(40, 512, 256, torch.float32, seed=66) == "generic"      # small layer
     assert _oracle_vs_gpu_matmul(64, 256, 130, torch.float32, seed=64) == "generic"      # K % 4 != 0
 
 

@@ -103,8 +103,9 @@ def test_workspace_size_functions_are_pure_host_code():
     dt = lib.mbnb_matmul_4bit_workspace_bytes_dt
     assert dt(4096, 4096, 4096, 4096, 0) == dt(4096, 4096, 4096, 4096, 1) == full(4096, 4096, 4096)   # 16-bit: the _kw query
     assert dt(4096, 4096, 4096, 4096, 2) == 4096 * 4096 * 4   # f32 weight dtype: the weight dequantised once as f32
-    assert dt(5, 4096, 4096, 4096, 2) == 4096 * 4096 * 4 + 16 * 5 * 4096 * 4   # 64 tiles of 64 x 64: 16 K slices of f32 partials
-    assert dt(4, 4096, 4096, 4096, 2) == 0                    # M <= 4: generic kernel
+    assert dt(17, 4096, 4096, 4096, 2) == 4096 * 4096 * 4 + 16 * 17 * 4096 * 4   # 64 tiles of 64 x 64: 16 K slices of f32 partials
+    assert dt(16, 4096, 4096, 4096, 2) == 0                   # two 8-row chunks of the generic kernel are cheaper
+    assert dt(64, 1024, 1024, 1024, 2) == 0 and dt(128, 1024, 1024, 1024, 2) > 0   # small layers: later
     assert dt(64, 256, 130, 192, 2) == 0                      # K % 4 != 0
     assert dt(300, 1000, 1028, 1088, 2) == 1000 * 1088 * 4 + 4 * 300 * 1000 * 4
     assert lib.mbnb_outlier_linear_workspace_bytes(4096, 4096) == 4096 * 4096 + 4 * 4096 + 32 * 4096
