@@ -130,7 +130,7 @@ __device__ __forceinline__ float block_absmax8(const float (&x)[8], int team) {
     return nan != 0.0f ? __builtin_bit_cast(float, 0x7FC00000u) : am;
 }
 
-template <typename T, int QT>
+template <typename T, int QT, int SPW>
 __global__ __launch_bounds__(256) void k_quantize_4bit(const T *__restrict__ A, int64_t rows, int64_t cols,
                                                       int64_t cols_padded, int blocksize,
                                                       const float *__restrict__ absmax_in,
@@ -138,50 +138,73 @@ __global__ __launch_bounds__(256) void k_quantize_4bit(const T *__restrict__ A, 
                                                       float *__restrict__ absmax_out, bool vec_ok, bool row_grid) {
     __shared__ uint8_t s_bins[256];
     __shared__ float s_thr[16];
-    fill_code_bins<QT>(s_bins, s_thr, threadIdx.x);
-    __syncthreads();
-    // one wave handles `span` = max(blocksize, 512) consecutive padded elements of one row
+    // one wave handles SPW spans of max(blocksize, 512) consecutive padded elements of one row
     const int lane = threadIdx.x & 63;
     const int span = blocksize > 512 ? blocksize : 512;
+    const int bs_shift = __builtin_ctz(blocksize);
     const int64_t spans_per_row = (cols_padded + span - 1) / span;
-    int64_t r, kspan;
-    if (row_grid) {   // blockIdx.x = row, blockIdx.y = group of four spans: no 64-bit divisions per thread
-        const int64_t sp = (int64_t)blockIdx.y * 4 + (threadIdx.x >> 6);
-        if (sp >= spans_per_row) return;
-        r = blockIdx.x;
-        kspan = sp * span;
-    } else {
-        const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-        if (wave >= rows * spans_per_row) return;
-        r = wave / spans_per_row;
-        kspan = (wave % spans_per_row) * span;
-    }
-    const int64_t nblk = cols_padded / blocksize;
+    const int64_t nblk = cols_padded >> bs_shift;
 
     if (blocksize <= 512) {
+        // the loads of every span go out before the code table is filled: the table's global read and the barrier sit
+        // under the data's HBM round trip instead of in front of it
         const int team = blocksize >> 3;  // lanes per block (1..64)
-        const int64_t k0 = kspan + (int64_t)lane * 8;
-        const bool active = k0 < cols_padded;
-        float x[8];
-        if (active) load8<T>(A, rows, cols, r, k0, vec_ok, x);
-        else {
+        int64_t r[SPW], k0[SPW];
+        bool active[SPW];
+        float x[SPW][8];
 #pragma unroll
-            for (int j = 0; j < 8; j++) x[j] = 0.0f;
-        }
-        const int64_t blk = active ? k0 / blocksize : 0;
-        float am;
-        if (absmax_in) {
-            am = active ? absmax_in[r * nblk + blk] : 1.0f;
-        } else {
-            am = block_absmax8(x, team);
-        }
-        if (!active) return;
-        if ((lane & (team - 1)) == 0) absmax_out[r * nblk + blk] = am;
-        uint32_t w = 0;
+        for (int i = 0; i < SPW; i++) {
+            if (row_grid) {   // blockIdx.x = row, blockIdx.y = group of 4 * SPW spans: no 64-bit divisions per thread
+                const int64_t sp = ((int64_t)blockIdx.y * SPW + i) * 4 + (threadIdx.x >> 6);
+                r[i] = blockIdx.x;
+                k0[i] = sp * span + (int64_t)lane * 8;
+                active[i] = sp < spans_per_row && k0[i] < cols_padded;
+            } else {
+                const int64_t wave = ((int64_t)blockIdx.x * SPW + i) * 4 + (threadIdx.x >> 6);
+                const bool in = wave < rows * spans_per_row;
+                r[i] = in ? wave / spans_per_row : 0;
+                k0[i] = (in ? (wave % spans_per_row) * span : 0) + (int64_t)lane * 8;
+                active[i] = in && k0[i] < cols_padded;
+            }
+            if (active[i]) load8<T>(A, rows, cols, r[i], k0[i], vec_ok, x[i]);
+            else {
 #pragma unroll
-        for (int j = 0; j < 8; j++) w |= nearest_code_lut<QT>(x[j] / am, s_bins, s_thr) << (4 * j);
-        *reinterpret_cast<uint32_t *>(packed + (r * cols_padded + k0) / 2) = w;
+                for (int j = 0; j < 8; j++) x[i][j] = 0.0f;
+            }
+        }
+        fill_code_bins<QT>(s_bins, s_thr, threadIdx.x);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < SPW; i++) {
+            const int64_t blk = active[i] ? (k0[i] >> bs_shift) : 0;
+            float am;
+            if (absmax_in) {
+                am = active[i] ? absmax_in[r[i] * nblk + blk] : 1.0f;
+            } else {
+                am = block_absmax8(x[i], team);
+            }
+            if (!active[i]) continue;
+            if ((lane & (team - 1)) == 0) absmax_out[r[i] * nblk + blk] = am;
+            uint32_t w = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) w |= nearest_code_lut<QT>(x[i][j] / am, s_bins, s_thr) << (4 * j);
+            *reinterpret_cast<uint32_t *>(packed + (r[i] * cols_padded + k0[i]) / 2) = w;
+        }
     } else {
+        fill_code_bins<QT>(s_bins, s_thr, threadIdx.x);
+        __syncthreads();
+        int64_t r, kspan;
+        if (row_grid) {
+            const int64_t sp = (int64_t)blockIdx.y * 4 + (threadIdx.x >> 6);
+            if (sp >= spans_per_row) return;
+            r = blockIdx.x;
+            kspan = sp * span;
+        } else {
+            const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+            if (wave >= rows * spans_per_row) return;
+            r = wave / spans_per_row;
+            kspan = (wave % spans_per_row) * span;
+        }
         // block larger than one wave step: pass 1 absmax over the block, pass 2 quantise
         const int64_t blk = kspan / blocksize;
         float am;
@@ -657,15 +680,23 @@ static int launch_quantize_4bit(const void *A, int64_t rows, int64_t cols, int64
     const int span = blocksize > 512 ? blocksize : 512;
     const int64_t spans_per_row = (cols_padded + span - 1) / span;
     const int64_t waves = rows * spans_per_row;
-    // wide rows: one grid row per matrix row (no per-thread division); narrow ones keep the flat wave index
+    // wide rows: one grid row per matrix row (no per-thread division); narrow ones keep the flat wave index.  Two spans
+    // per wave (both loads in flight before the first is consumed) once a row has 8 of them and blocks fit a wave step.
     const bool row_grid = spans_per_row >= 4 && (spans_per_row + 3) / 4 <= 65535 && rows <= 0x7FFFFFFF;
-    const dim3 grid = row_grid ? dim3((unsigned)rows, (unsigned)((spans_per_row + 3) / 4)) : dim3((unsigned)((waves + 3) / 4));
-    if (qt == MBNB_NF4)
-        hipLaunchKernelGGL((k_quantize_4bit<T, MBNB_NF4>), grid, dim3(256), 0, st, a, rows, cols, cols_padded,
-                           blocksize, absmax_in, packed, absmax_out, vec_ok, row_grid);
-    else
-        hipLaunchKernelGGL((k_quantize_4bit<T, MBNB_FP4>), grid, dim3(256), 0, st, a, rows, cols, cols_padded,
-                           blocksize, absmax_in, packed, absmax_out, vec_ok, row_grid);
+    const bool two = row_grid && blocksize <= 512 && spans_per_row >= 8;
+    const int64_t per_wg = two ? 8 : 4;
+    const dim3 grid = row_grid ? dim3((unsigned)rows, (unsigned)((spans_per_row + per_wg - 1) / per_wg)) : dim3((unsigned)((waves + 3) / 4));
+#define MBNB_Q4(QT, SPW)                                                                                           \
+    hipLaunchKernelGGL((k_quantize_4bit<T, QT, SPW>), grid, dim3(256), 0, st, a, rows, cols, cols_padded, blocksize, \
+                       absmax_in, packed, absmax_out, vec_ok, row_grid)
+    if (qt == MBNB_NF4) {
+        if (two) MBNB_Q4(MBNB_NF4, 2);
+        else MBNB_Q4(MBNB_NF4, 1);
+    } else {
+        if (two) MBNB_Q4(MBNB_FP4, 2);
+        else MBNB_Q4(MBNB_FP4, 1);
+    }
+#undef MBNB_Q4
     return check_launch("quantize_4bit");
 }
 
