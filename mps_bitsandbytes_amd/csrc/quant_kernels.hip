@@ -130,6 +130,68 @@ __device__ __forceinline__ float block_absmax8(const float (&x)[8], int team) {
     return nan != 0.0f ? __builtin_bit_cast(float, 0x7FC00000u) : am;
 }
 
+
+// Outside the interval where f32 distances to the 16 codes are strictly ordered -- |xn| >= 2^22, reachable only with a
+// caller-supplied absmax far below |x|, or inf -- the reference's argmin over |xn - code| (functional.py:239-240) no longer
+// returns the nearest code: the distances round to the same f32 value and the FIRST index of the tie wins (2^23 -> 13, 2^25 ->
+// 0, inf -> 0).  There the distances are evaluated literally.
+template <int QT> __device__ __forceinline__ uint32_t nearest_code_literal(float xn) {
+    float best = fabsf(xn - code_value<QT>(0));
+    uint32_t idx = 0;
+#pragma unroll
+    for (int i = 1; i < 16; i++) {
+        const float d = fabsf(xn - code_value<QT>(i));
+        if (d < best) {
+            best = d;
+            idx = (uint32_t)i;
+        }
+    }
+    return idx;
+}
+
+// x / absmax for the 8 values a lane holds of one block (functional.py:236, an f32 true division -- its bits decide which side of
+// a threshold a value falls).  The compiler expands every `x / am` into the IEEE sequence
+//   r0 = rcp(am); r1 = fma(fma(-am, r0, 1), r0, r0); q0 = x r1; q1 = fma(fma(-am, q0, x), r1, q0); q = fma(fma(-am, q1, x), r1, q1)
+// wrapped in v_div_scale / v_div_fmas / v_div_fixup, ~11 VALU per element of a VALU-bound kernel.  The reciprocal part depends
+// on am alone, so it is computed once per lane; the per-element part (1 mul + 4 fma) is the same instruction chain on the
+// same operands, hence the same bits, whenever the scale instructions would have been the identity: am in [2^-60, 2^60]
+// (no scaling of the denominator) and |x| <= am.  What they additionally rescue -- quotients or numerators below 2^-100 --
+// lies deep inside the zero code's interval, where any tiny value selects the same index.  Outside that range of am
+// (wave-uniform test) the plain division runs.
+struct SharedDiv {
+    float am, r1;
+    __device__ __forceinline__ float operator()(float x) const {
+        const float q0 = x * r1;
+        const float q1 = __builtin_fmaf(__builtin_fmaf(-am, q0, x), r1, q0);
+        return __builtin_fmaf(__builtin_fmaf(-am, q1, x), r1, q1);
+    }
+};
+__device__ __forceinline__ SharedDiv shared_div(float am) {
+    const float r0 = __builtin_amdgcn_rcpf(am);
+    return SharedDiv{am, __builtin_fmaf(__builtin_fmaf(-am, r0, 1.0f), r0, r0)};
+}
+__device__ __forceinline__ bool shared_div_ok(float am) {   // wave-uniform: every lane's absmax in the unscaled range
+    return __builtin_amdgcn_ballot_w64(!(am >= 0x1p-60f && am <= 0x1p60f)) == 0;
+}
+// own_absmax: am is the block's own max |x| (so |x| <= am); a caller-supplied absmax may be smaller than |x| by any factor and
+// keeps the plain division.
+template <int QT> __device__ __forceinline__ uint32_t quantize8(const float (&x)[8], float am, const uint8_t *bins, const float *thr,
+                                                              bool own_absmax) {
+    uint32_t w = 0;
+    if (own_absmax && shared_div_ok(am)) {
+        const SharedDiv d = shared_div(am);
+#pragma unroll
+        for (int j = 0; j < 8; j++) w |= nearest_code_lut<QT>(d(x[j]), bins, thr) << (4 * j);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const float q = x[j] / am;
+            w |= ((fabsf(q) < 0x1p22f) ? nearest_code_lut<QT>(q, bins, thr) : nearest_code_literal<QT>(q)) << (4 * j);
+        }
+    }
+    return w;
+}
+
 template <typename T, int QT, int SPW>
 __global__ __launch_bounds__(256) void k_quantize_4bit(const T *__restrict__ A, int64_t rows, int64_t cols,
                                                       int64_t cols_padded, int blocksize,
@@ -185,9 +247,7 @@ __global__ __launch_bounds__(256) void k_quantize_4bit(const T *__restrict__ A, 
             }
             if (!active[i]) continue;
             if ((lane & (team - 1)) == 0) absmax_out[r[i] * nblk + blk] = am;
-            uint32_t w = 0;
-#pragma unroll
-            for (int j = 0; j < 8; j++) w |= nearest_code_lut<QT>(x[i][j] / am, s_bins, s_thr) << (4 * j);
+            const uint32_t w = quantize8<QT>(x[i], am, s_bins, s_thr, absmax_in == nullptr);
             *reinterpret_cast<uint32_t *>(packed + (r[i] * cols_padded + k0[i]) / 2) = w;
         }
     } else {
@@ -230,9 +290,7 @@ __global__ __launch_bounds__(256) void k_quantize_4bit(const T *__restrict__ A, 
             const int64_t k0 = kspan + s + lane * 8;
             float x[8];
             load8<T>(A, rows, cols, r, k0, vec_ok, x);
-            uint32_t w = 0;
-#pragma unroll
-            for (int j = 0; j < 8; j++) w |= nearest_code_lut<QT>(x[j] / am, s_bins, s_thr) << (4 * j);
+            const uint32_t w = quantize8<QT>(x, am, s_bins, s_thr, absmax_in == nullptr);
             *reinterpret_cast<uint32_t *>(packed + (r * cols_padded + k0) / 2) = w;
         }
     }
@@ -273,9 +331,7 @@ __global__ __launch_bounds__(256) void k_quantize_4bit_dq(const T *__restrict__ 
         const float am = block_absmax8(x, team);
         if (tl == 0) s_am[it * bpi + tb] = active ? am : 0.0f;
         if (active) {
-            uint32_t w = 0;
-#pragma unroll
-            for (int j = 0; j < 8; j++) w |= nearest_code_lut<QT>(x[j] / am, s_bins, s_thr) << (4 * j);
+            const uint32_t w = quantize8<QT>(x, am, s_bins, s_thr, true);
             *reinterpret_cast<uint32_t *>(packed + (r * cols_padded + k0) / 2) = w;
         }
     }
@@ -317,7 +373,8 @@ __global__ __launch_bounds__(256) void k_quantize_4bit_tiny(const T *__restrict_
         }
         if (k % blocksize == 0) absmax_out[r * nblk + blk] = am;
         float x = k < cols ? to_f32(A[r * cols + k]) : 0.0f;
-        byte |= nearest_code<QT>(x / am) << (4 * e);
+        const float q = x / am;
+        byte |= ((fabsf(q) < 0x1p22f) ? nearest_code<QT>(q) : nearest_code_literal<QT>(q)) << (4 * e);
     }
     packed[j] = (uint8_t)byte;
 }

@@ -28,7 +28,7 @@ from mps_bitsandbytes_amd import synthetic  # noqa: E402
 
 
 def main():
-    arrays, manifest = {}, {"dequant_absmax": [], "config_from_dict": [], "quant4_nan": []}
+    arrays, manifest = {}, {"dequant_absmax": [], "config_from_dict": [], "quant4_nan": [], "quant4_absmax_in": []}
     # NaN inside a quantisation block: the reference's abs().max() propagates it into absmax and argmin over
     # all-NaN distances returns index 0 for the whole block; neighbouring blocks are untouched
     for i, (dt, qt, bs, shape) in enumerate([(torch.float16, "nf4", 64, (4, 256)), (torch.float32, "fp4", 64, (3, 192)),
@@ -44,6 +44,23 @@ def main():
         arrays[k + "absmax"] = st.absmax.float().contiguous().numpy().view(np.uint32)
         manifest["quant4_nan"].append({"id": i, "dtype": {torch.float16: "f16", torch.bfloat16: "bf16", torch.float32: "f32"}[dt],
                                        "quant_type": qt, "blocksize": bs, "shape": list(shape)})
+    # caller-supplied absmax (functional.py:231: used as the normaliser when given) far below |x|: quotients of 2^0 .. 2^40 and
+    # inf.  From |xn| ~ 2^23 the f32 distances to the codes tie and argmin returns the FIRST tied index, not the nearest code
+    for i, (dt, qt, bs, shape, am) in enumerate([(torch.float32, "nf4", 64, (41, 128), 2.0 ** -10), (torch.float32, "fp4", 64, (41, 128), 2.0 ** -10),
+                                                 (torch.bfloat16, "nf4", 32, (41, 64), 2.0 ** -30), (torch.float16, "fp4", 4, (16, 64), 2.0 ** -24)]):
+        x = synthetic.normal(shape, torch.float32, seed=500 + i)
+        e = torch.arange(shape[0]).double() - (10 if dt != torch.float16 else 14)
+        x = (x * torch.pow(torch.tensor(2.0, dtype=torch.float64), e).float().unsqueeze(1)).to(dt)
+        if dt == torch.float32:
+            x[-1, :8] = torch.tensor([float("inf"), float("-inf"), 3e38, -3e38, 2.0 ** 13, -(2.0 ** 13), 2.0 ** 15 + 1, 0.0])
+        nblocks = x.numel() // bs
+        absmax = torch.full((shape[0], shape[1] // bs), am, dtype=torch.float32)
+        packed, st = ref.functional.quantize_4bit(x.clone(), absmax=absmax.clone(), blocksize=bs, quant_type=qt)
+        k = f"qa{i}_"
+        arrays[k + "x"] = x.view(torch.int16).numpy().view(np.uint16) if dt != torch.float32 else x.numpy().view(np.uint32)
+        arrays[k + "packed"] = packed.numpy()
+        manifest["quant4_absmax_in"].append({"id": i, "dtype": {torch.float16: "f16", torch.bfloat16: "bf16", torch.float32: "f32"}[dt],
+                                             "quant_type": qt, "blocksize": bs, "shape": list(shape), "absmax": am, "nblocks": nblocks})
     cases = [
         dict(rows=4, num_blocks=600, dq_blocks=3, blocksize=256, code="int8"),     # ragged last block (88 codes)
         dict(rows=3, num_blocks=512, dq_blocks=2, blocksize=256, code="uint8"),

@@ -975,6 +975,40 @@ def test_quantize_4bit_nan_blocks_match_the_reference():
     check_quant4_nan(q)
 
 
+def test_quantize_4bit_supplied_absmax_ties_match_the_reference():
+    """A caller-supplied absmax far below |x|: from |x / absmax| ~ 2^23 the reference's argmin over f32 distances returns the
+    first index of a tie, not the nearest code (goldens produced by the reference, g8_misc.npz)."""
+    from tests.test_oracle_misc_golden import check_quant4_absmax_in
+    check_quant4_absmax_in(lambda x, am, bs, qt: bnb.quantize_4bit(x.to(DEV), absmax=am.to(DEV), blocksize=bs, quant_type=qt)[0])
+
+
+@pytest.mark.parametrize("dt,emin,emax", [(torch.float32, -90, 90), (torch.bfloat16, -90, 90), (torch.float16, -12, 14)])
+def test_quantize_4bit_dynamic_range_bit_exact(dt, emin, emax):
+    """x / absmax is an f32 true division in the reference (functional.py:236); the kernels compute the reciprocal part once
+    per lane and the per-element correction chain of the IEEE expansion while absmax is in [2^-60, 2^60], the plain division
+    outside.  Rows scaled by 2^e across (and beyond) that range, 65 536 distinct absmax mantissas, both code tables, a block
+    larger than a wave step, the one-launch double-quant kernel and a caller-supplied absmax: packed bytes and absmax equal
+    the oracle's."""
+    rows, cols = 1024, 2048
+    x = synthetic.normal((rows, cols), torch.float32, seed=91)
+    e = torch.arange(rows) % (emax - emin + 1) + emin
+    x = (x * torch.pow(torch.tensor(2.0, dtype=torch.float64), e.double()).float().unsqueeze(1)).to(dt)
+    assert torch.isfinite(x.float()).all()
+    for qt, bs, cs in (("nf4", 64, False), ("fp4", 64, False), ("nf4", 2048, False), ("nf4", 32, True), ("fp4", 512, True)):
+        o_packed, o_absmax, o_st2 = oracle.quantize_4bit(x, bs, qt, cs)
+        packed, st = bnb.quantize_4bit(x.to(DEV), blocksize=bs, quant_type=qt, compress_statistics=cs)
+        assert n_mismatch(packed.cpu(), o_packed) == 0, (qt, bs, cs)
+        if cs:
+            assert torch.equal(st.absmax.cpu(), o_absmax) and bits_equal(st.state2.absmax.cpu(), o_st2[0])
+        else:
+            assert bits_equal(st.absmax.cpu(), o_absmax)
+    # a caller-supplied absmax far below |x| (quotients up to 2^60 and beyond): plain division, same bytes as the oracle
+    small = torch.full((rows * cols // 64,), 2.0 ** -20 if dt != torch.float16 else 2.0 ** -10, dtype=torch.float32)
+    packed, _ = bnb.quantize_4bit(x.to(DEV), absmax=small.to(DEV), blocksize=64, quant_type="nf4")
+    o_packed, _, _ = oracle.quantize_4bit(x, 64, "nf4", False, absmax=small)
+    assert n_mismatch(packed.cpu(), o_packed) == 0
+
+
 @pytest.mark.parametrize("bs", [8, 16, 64, 128, 512, 1024])
 def test_quantize_4bit_fused_double_quant_equals_two_launches(bs):
     """compress_statistics=True in one launch (mbnb_quantize_4bit_dq, 8 <= blocksize <= 512) must give exactly what

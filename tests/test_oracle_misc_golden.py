@@ -53,5 +53,27 @@ def check_quant4_nan(quantize):
         assert torch.equal(torch.isnan(a), nan) and torch.equal(a[~nan].view(torch.int32), g_absmax[~nan].view(torch.int32)), c
 
 
+def check_quant4_absmax_in(quantize):
+    """quantize(x, absmax f32 [nblocks], blocksize, quant_type) -> packed u8, against the reference run with a caller-supplied
+    absmax far below |x| (functional.py:231,236-240): quotients up to 2^40 and inf, where argmin over tied f32 distances
+    returns the first tied index (13 / 14 / 0), not the nearest code."""
+    from tests.goldenio import DT
+    npz = np.load(os.path.join(HERE, "g8_misc.npz"))
+    assert len(MAN["quant4_absmax_in"]) == 4
+    for c in MAN["quant4_absmax_in"]:
+        k = f"qa{c['id']}_"
+        x = from_bits(npz[k + "x"], DT[c["dtype"]]).reshape(c["shape"])
+        absmax = torch.full((c["nblocks"],), c["absmax"], dtype=torch.float32)
+        packed = quantize(x, absmax, c["blocksize"], c["quant_type"])
+        g_packed = torch.from_numpy(np.ascontiguousarray(npz[k + "packed"]))
+        lo = g_packed & 15
+        assert int(((lo == 13) | (lo == 14)).sum()) > 0 or c["quant_type"] == "fp4", c     # the tie region is in the data
+        assert torch.equal(packed.cpu().view(-1), g_packed.view(-1)), c
+
+
+def test_oracle_quantize_4bit_with_supplied_absmax_ties_like_the_reference():
+    check_quant4_absmax_in(lambda x, am, bs, qt: oracle.quantize_4bit(x, bs, qt, False, absmax=am)[0])
+
+
 def test_oracle_quantize_4bit_propagates_nan_like_the_reference():
     check_quant4_nan(lambda x, bs, qt: oracle.quantize_4bit(x, bs, qt)[:2])
