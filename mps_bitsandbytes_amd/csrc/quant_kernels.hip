@@ -388,34 +388,44 @@ __global__ __launch_bounds__(256) void k_dequantize_4bit(const uint8_t *__restri
                                                         int64_t rows, int64_t cols, int64_t cols_padded,
                                                         int blocksize, T *__restrict__ out, bool vec_ok, bool row_grid) {
     __shared__ float lut[16];
-    fill_code_lut<QT>(lut, threadIdx.x);
-    __syncthreads();
     const int64_t groups_per_row = (cols + 7) / 8;
+    const int bs_shift = __builtin_ctz(blocksize);   // a power of two (checked at the boundary): shifts, not 64-bit divisions
     int64_t r, k0;
+    bool active;
     if (row_grid) {   // blockIdx.x = row, blockIdx.y = 256 groups of 8 values: no 64-bit divisions per thread
         const int64_t gc = (int64_t)blockIdx.y * 256 + threadIdx.x;
-        if (gc >= groups_per_row) return;
+        active = gc < groups_per_row;
         r = blockIdx.x;
-        k0 = gc * 8;
+        k0 = active ? gc * 8 : 0;
     } else {
         const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-        if (g >= rows * groups_per_row) return;
-        r = g / groups_per_row;
-        k0 = (g % groups_per_row) * 8;
+        active = g < rows * groups_per_row;
+        r = active ? g / groups_per_row : 0;
+        k0 = active ? (g % groups_per_row) * 8 : 0;
     }
-    const int64_t nblk = cols_padded / blocksize;
+    const int64_t nblk = cols_padded >> bs_shift;
     const int64_t flat0 = r * cols_padded + k0;  // even (cols_padded even, k0 multiple of 8)
+    const bool dword = (cols_padded & 7) == 0;
+    // the packed dword and its absmax are requested before the code table is filled: the table's barrier sits under the
+    // HBM round trip instead of in front of it
+    uint32_t w = 0;
+    float a = 0.0f;
+    if (active && dword) {
+        w = *reinterpret_cast<const uint32_t *>(packed + flat0 / 2);
+        if (blocksize >= 8) a = load_absmax<NESTED>(am, r * nblk + (k0 >> bs_shift));
+    }
+    fill_code_lut<QT>(lut, threadIdx.x);
+    __syncthreads();
+    if (!active) return;
     float v[8];
-    if ((cols_padded & 7) == 0) {
-        const uint32_t w = *reinterpret_cast<const uint32_t *>(packed + flat0 / 2);
+    if (dword) {
         if (blocksize >= 8) {
-            const float a = load_absmax<NESTED>(am, r * nblk + k0 / blocksize);
 #pragma unroll
             for (int j = 0; j < 8; j++) v[j] = lut[(w >> (4 * j)) & 15] * a;
         } else {
 #pragma unroll
             for (int j = 0; j < 8; j++)
-                v[j] = lut[(w >> (4 * j)) & 15] * load_absmax<NESTED>(am, r * nblk + (k0 + j) / blocksize);
+                v[j] = lut[(w >> (4 * j)) & 15] * load_absmax<NESTED>(am, r * nblk + ((k0 + j) >> bs_shift));
         }
     } else {
 #pragma unroll
@@ -424,7 +434,7 @@ __global__ __launch_bounds__(256) void k_dequantize_4bit(const uint8_t *__restri
             if (k < cols) {
                 const uint8_t b = packed[(flat0 + j) / 2];
                 const int idx = ((flat0 + j) & 1) ? (b >> 4) : (b & 15);
-                v[j] = lut[idx] * load_absmax<NESTED>(am, r * nblk + k / blocksize);
+                v[j] = lut[idx] * load_absmax<NESTED>(am, r * nblk + (k >> bs_shift));
             } else v[j] = 0.0f;
         }
     }
