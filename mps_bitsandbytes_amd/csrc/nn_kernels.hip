@@ -228,6 +228,75 @@ __global__ __launch_bounds__(256) void k_quantize_rowwise_masked(const T *__rest
     for (int64_t c = nvec * 8 + threadIdx.x; c < cols; c += 256) orow[c] = mask[c] ? (int8_t)0 : quant_i8(to_f32(row[c]), s);
 }
 
+// The same for 16-bit rows of up to 8192 columns on the vector path: the row's 16-byte pieces are requested BEFORE the column
+// mask is built (its two barriers and the index loads sit under the row's HBM round trip) and stay in registers, with the
+// outlier columns zeroed in place, for both the absmax pass and the quantise pass -- the row is read from memory once.
+template <typename T>
+__global__ __launch_bounds__(256) void k_quantize_rowwise_masked_regs(const T *__restrict__ A, int64_t cols,
+                                                                     const int64_t *__restrict__ oidx, int64_t n_out,
+                                                                     int8_t *__restrict__ out, float *__restrict__ scales,
+                                                                     T *__restrict__ xo, int64_t ldxo) {
+    static_assert(sizeof(T) == 2, "16-bit rows");
+    extern __shared__ __attribute__((aligned(8))) uint8_t mask[];
+    __shared__ float red[4];
+    const int64_t r = blockIdx.x;
+    const T *row = A + r * cols;
+    const int nvec = (int)(cols / 8);   // cols % 8 == 0, nvec <= 1024
+    u32x4 raw[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int g = threadIdx.x + 256 * i;
+        raw[i] = g < nvec ? *reinterpret_cast<const u32x4 *>(row + (int64_t)g * 8) : u32x4{0u, 0u, 0u, 0u};
+    }
+    for (int64_t c = (int64_t)threadIdx.x * 8; c < cols; c += 256 * 8) *reinterpret_cast<u32x2 *>(mask + c) = u32x2{0u, 0u};
+    __syncthreads();
+    for (int64_t j = threadIdx.x; j < n_out; j += 256)
+        if (oidx[j] >= 0 && oidx[j] < cols) mask[oidx[j]] = 1;
+    __syncthreads();
+    float am = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int g = threadIdx.x + 256 * i;
+        if (g < nvec) {
+            const u32x2 mk = *reinterpret_cast<const u32x2 *>(mask + (int64_t)g * 8);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {   // dword j = elements 2j (low half) and 2j + 1 (high half)
+                const uint32_t m2 = (mk[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+                if (m2 & 0x00FFu) raw[i][j] &= 0xFFFF0000u;
+                if (m2 & 0xFF00u) raw[i][j] &= 0x0000FFFFu;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) am = fmaxf(am, fmaxf(fabsf(unpack_lo<T>(raw[i][j])), fabsf(unpack_hi<T>(raw[i][j]))));
+    }
+    am = wave_max(am);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = am;
+    __syncthreads();
+    am = fmaxf(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])), 1e-8f);
+    if (threadIdx.x == 0) scales[r] = am;
+    if (xo != nullptr)
+        for (int64_t j = threadIdx.x; j < ldxo; j += 256) {
+            const int64_t c = j < n_out ? oidx[j] : -1;
+            xo[r * ldxo + j] = (c >= 0 && c < cols) ? row[c] : from_f32<T>(0.0f);
+        }
+    const float s = rscale127(am);
+    int8_t *orow = out + r * cols;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int g = threadIdx.x + 256 * i;
+        if (g >= nvec) continue;
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            lo |= (uint32_t)(uint8_t)quant_i8(unpack_lo<T>(raw[i][j]), s) << (16 * j);
+            lo |= (uint32_t)(uint8_t)quant_i8(unpack_hi<T>(raw[i][j]), s) << (16 * j + 8);
+            hi |= (uint32_t)(uint8_t)quant_i8(unpack_lo<T>(raw[i][2 + j]), s) << (16 * j);
+            hi |= (uint32_t)(uint8_t)quant_i8(unpack_hi<T>(raw[i][2 + j]), s) << (16 * j + 8);
+        }
+        *reinterpret_cast<u32x2 *>(orow + (int64_t)g * 8) = u32x2{lo, hi};
+    }
+}
+
 // out[m, n] <- RNE(RNE(out[m, n] + RNE(sum_j x[m, idx_j] * ow[n, j])) + bias[n])   (nn/outlier_aware.py:141-143, :110-111);
 // without outliers only the bias add.  A workgroup owns 16 rows x 512 columns, a thread 16 rows x 2 consecutive
 // columns (4-byte accesses to `out` for 16-bit types; its outlier weights come as 16-byte loads when n_out % 8 == 0).  The rows' outlier activations are gathered once into LDS
@@ -356,8 +425,17 @@ static int launch_outlier_linear(const void *X, int64_t M, int64_t K, const int8
         return MBNB_ERR_ARG;
     }
     const bool vec_ok = (K % 8 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
-    hipLaunchKernelGGL(k_quantize_rowwise_masked<T>, dim3((unsigned)M), dim3(256), mask_lds, st, static_cast<const T *>(X), M, K,
-                       oidx, n_out, xq, xs, xo, ldx, vec_ok);
+    if constexpr (sizeof(T) == 2) {
+        if (vec_ok && K <= 8192)   // the row fits the workgroup's registers: read once
+            hipLaunchKernelGGL(k_quantize_rowwise_masked_regs<T>, dim3((unsigned)M), dim3(256), mask_lds, st, static_cast<const T *>(X), K,
+                               oidx, n_out, xq, xs, xo, ldx);
+        else
+            hipLaunchKernelGGL(k_quantize_rowwise_masked<T>, dim3((unsigned)M), dim3(256), mask_lds, st, static_cast<const T *>(X), M, K,
+                               oidx, n_out, xq, xs, xo, ldx, vec_ok);
+    } else {
+        hipLaunchKernelGGL(k_quantize_rowwise_masked<T>, dim3((unsigned)M), dim3(256), mask_lds, st, static_cast<const T *>(X), M, K,
+                           oidx, n_out, xq, xs, xo, ldx, vec_ok);
+    }
     int rc = check_launch("outlier_linear(quantize)");
     if (rc) return rc;
     // the 256 x 256 kernel folds the outlier columns (one MFMA per tile and chunk of 16 outliers) and the bias into its

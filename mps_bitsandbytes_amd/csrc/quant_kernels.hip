@@ -529,6 +529,50 @@ int dequant_absmax_dispatch(const void *q, int q_kind, int64_t rows, int64_t num
 // =====================================================================================
 // quantize_rowwise: one workgroup per row (pass 1 absmax, pass 2 quantise; the row stays in L2)
 // =====================================================================================
+// Rows of up to 8192 16-bit values (vector path): the row is read ONCE -- a thread keeps its (up to four) 16-byte pieces in
+// registers between the absmax pass and the quantise pass.  Same arithmetic as k_quantize_rowwise below.
+template <typename T>
+__global__ __launch_bounds__(256) void k_quantize_rowwise_regs(const T *__restrict__ A, int64_t cols, int8_t *__restrict__ out,
+                                                              float *__restrict__ scales) {
+    static_assert(sizeof(T) == 2, "16-bit rows");
+    __shared__ float red[4];
+    const int64_t r = blockIdx.x;
+    const T *row = A + r * cols;
+    const int nvec = (int)(cols / 8);   // cols % 8 == 0, nvec <= 1024
+    u32x4 raw[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int g = threadIdx.x + 256 * i;
+        raw[i] = g < nvec ? *reinterpret_cast<const u32x4 *>(row + (int64_t)g * 8) : u32x4{0u, 0u, 0u, 0u};
+    }
+    float am = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) am = fmaxf(am, fmaxf(fabsf(unpack_lo<T>(raw[i][j])), fabsf(unpack_hi<T>(raw[i][j]))));
+    am = wave_max(am);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = am;
+    __syncthreads();
+    am = fmaxf(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])), 1e-8f);
+    if (threadIdx.x == 0) scales[r] = am;  // the absmax itself, functional.py:617-618
+    const float s = rscale127(am);         // functional.py:621
+    int8_t *orow = out + r * cols;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int g = threadIdx.x + 256 * i;
+        if (g >= nvec) continue;
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            lo |= (uint32_t)(uint8_t)quant_i8(unpack_lo<T>(raw[i][j]), s) << (16 * j);
+            lo |= (uint32_t)(uint8_t)quant_i8(unpack_hi<T>(raw[i][j]), s) << (16 * j + 8);
+            hi |= (uint32_t)(uint8_t)quant_i8(unpack_lo<T>(raw[i][2 + j]), s) << (16 * j);
+            hi |= (uint32_t)(uint8_t)quant_i8(unpack_hi<T>(raw[i][2 + j]), s) << (16 * j + 8);
+        }
+        *reinterpret_cast<u32x2 *>(orow + (int64_t)g * 8) = u32x2{lo, hi};
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_quantize_rowwise(const T *__restrict__ A, int64_t rows, int64_t cols,
                                                          int8_t *__restrict__ out, float *__restrict__ scales,
@@ -859,6 +903,11 @@ int quantize_rowwise_dispatch(const void *A, int dtype, int64_t rows, int64_t co
                               hipStream_t st) {
     const bool vec_ok = aligned16(A) && aligned16(out) && (cols % 8 == 0);
     const unsigned grid = (unsigned)rows;
+    if (vec_ok && cols <= 8192 && dtype != MBNB_F32) {   // the row fits the registers of one workgroup: one pass over memory
+        if (dtype == MBNB_F16) hipLaunchKernelGGL(k_quantize_rowwise_regs<f16_t>, dim3(grid), dim3(256), 0, st, static_cast<const f16_t *>(A), cols, out, scales);
+        else hipLaunchKernelGGL(k_quantize_rowwise_regs<bf16_t>, dim3(grid), dim3(256), 0, st, static_cast<const bf16_t *>(A), cols, out, scales);
+        return check_launch("quantize_rowwise");
+    }
     switch (dtype) {
         case MBNB_F16: hipLaunchKernelGGL(k_quantize_rowwise<f16_t>, dim3(grid), dim3(256), 0, st, static_cast<const f16_t *>(A), rows, cols, out, scales, vec_ok); break;
         case MBNB_BF16: hipLaunchKernelGGL(k_quantize_rowwise<bf16_t>, dim3(grid), dim3(256), 0, st, static_cast<const bf16_t *>(A), rows, cols, out, scales, vec_ok); break;
