@@ -489,7 +489,8 @@ __global__ __launch_bounds__(256) void k_dequantize_blockwise(const int8_t *__re
                                                              T *__restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= numel) return;
-    const float scale = absmax[i / blocksize] / 127.0f;  // functional.py:592
+    const bool pow2 = (blocksize & (blocksize - 1)) == 0;   // a shift instead of a 64-bit division where the blocksize allows
+    const float scale = absmax[pow2 ? (i >> __builtin_ctz(blocksize)) : i / blocksize] / 127.0f;  // functional.py:592
     out[i] = from_f32<T>((float)q[i] * scale);
 }
 
@@ -877,8 +878,16 @@ int dequantize_4bit_dispatch(const uint8_t *packed, const AbsmaxView &am, int64_
 #undef MBNB_DQ
 }
 
+int quantize_rowwise_dispatch(const void *, int, int64_t, int64_t, int8_t *, float *, hipStream_t);
+int dequantize_rowwise_dispatch(const int8_t *, const float *, int64_t, int64_t, int, void *, hipStream_t);
+
 int quantize_blockwise_dispatch(const void *A, int dtype, int64_t numel, int blocksize, const float *absmax_in,
                                 int8_t *out, float *absmax_out, hipStream_t st) {
+    // whole blocks with their own absmax ARE quantize_rowwise over [numel / blocksize, blocksize] (functional.py:513-521 and
+    // :617-622: the same clamp, the same 127 / absmax, the same round and clamp; both return the absmax itself): its
+    // vectorised / single-pass kernels instead of the scalar one below
+    if (absmax_in == nullptr && numel > 0 && numel % blocksize == 0 && blocksize >= 64)
+        return quantize_rowwise_dispatch(A, dtype, numel / blocksize, blocksize, out, absmax_out, st);
     const unsigned grid = (unsigned)((numel + blocksize - 1) / blocksize);
     switch (dtype) {
         case MBNB_F16: hipLaunchKernelGGL(k_quantize_blockwise<f16_t>, dim3(grid), dim3(256), 0, st, static_cast<const f16_t *>(A), numel, blocksize, absmax_in, out, absmax_out); break;
@@ -890,6 +899,10 @@ int quantize_blockwise_dispatch(const void *A, int dtype, int64_t numel, int blo
 
 int dequantize_blockwise_dispatch(const int8_t *q, int64_t numel, const float *absmax, int blocksize, int out_dtype,
                                   void *out, hipStream_t st) {
+    // whole blocks of >= 1024 values: dequantize_rowwise over [numel / blocksize, blocksize] (functional.py:592-594 and :635:
+    // q.float() * (absmax / 127)), 16 values per thread
+    if (numel > 0 && numel % blocksize == 0 && blocksize >= 1024 && blocksize % 16 == 0 && numel / blocksize < 65536)
+        return dequantize_rowwise_dispatch(q, absmax, numel / blocksize, blocksize, out_dtype, out, st);
     const unsigned grid = (unsigned)((numel + 255) / 256);
     switch (out_dtype) {
         case MBNB_F16: hipLaunchKernelGGL(k_dequantize_blockwise<f16_t>, dim3(grid), dim3(256), 0, st, q, numel, absmax, blocksize, static_cast<f16_t *>(out)); break;

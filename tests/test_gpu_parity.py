@@ -448,6 +448,21 @@ def test_g5_rowwise_and_blockwise_bit_exact(golden):
         assert n_mismatch(d.cpu(), from_bits(npz[k + "deq"], DT[c["dtype"]])) == 0, k
 
 
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("numel,bs", [(1 << 20, 4096), (1 << 20, 2048), (3 * 8192 + 5, 8192), (1 << 18, 64), (100 * 1000, 100),
+                                      (1 << 16, 16384), (4096 * 24, 4096)])
+def test_blockwise_sizes_and_kernel_forms_bit_exact(dt, numel, bs):
+    """quantize_blockwise / dequantize_blockwise (functional.py:469-600) over whole blocks run on the row-wise kernels (same
+    arithmetic: single-pass for 16-bit blocks of <= 8192 values, 16 values per thread on the way back), ragged tails and
+    blocksizes that are no power of two on the scalar kernels: all equal the oracle bit for bit."""
+    x = synthetic.normal((numel,), dt, seed=19 + bs % 97)
+    oq, oa = oracle.quantize_blockwise(x, bs)
+    q, st = bnb.quantize_blockwise(x.to(DEV), blocksize=bs)
+    assert n_mismatch(q.cpu(), oq) == 0 and bits_equal(st.absmax.cpu(), oa)
+    d = bnb.dequantize_blockwise(q, st)
+    assert d.dtype == dt and n_mismatch(d.cpu(), oracle.dequantize_blockwise(oq, oa, bs, dt)) == 0
+
+
 def test_g5_double_quant_bit_exact(golden):
     npz = golden.npz("g5_int8.npz")
     for c in [c for c in golden.manifest["g5"] if c["kind"] == "double_quant"]:
