@@ -767,6 +767,128 @@ __global__ __launch_bounds__(256) void k_double_quant(const T *__restrict__ A, i
     out_col[i] = quant_i8(x, rscale127(col_stats[i % cols]));  // functional.py:858-861
 }
 
+// ---- double_quant, vector form (cols % 8 == 0, 16-byte aligned A, 8-byte aligned outputs).  The scalar kernels above cost
+// 63 us at 4096^2: two 64-bit divisions and two IEEE divisions (127 / stat) per element, 2-byte loads, A read three times
+// by four launches.  Here: ONE statistics pass (k_rowcol_absmax8: atomic maxima, non-negative floats order like their bit
+// patterns), then one quantise pass (a thread owns 8 columns x 8 rows: the eight column scales 127 / stat are divided once
+// and reused for the rows; 16-byte loads, all eight in flight, 8-byte stores; it also applies and writes back the 1e-8 clamp).  Same values as the scalar path:
+// max is exact in any order, and each output is quant_i8(x, rscale127(stat)) of the same two operands.
+__global__ __launch_bounds__(256) void k_zero_stats2(float *__restrict__ a, int64_t na, float *__restrict__ b, int64_t nb) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (a && i < na) a[i] = 0.0f;
+    if (b && i < nb) b[i] = 0.0f;
+}
+// A workgroup owns 128 rows x 128 columns: a wave's load instruction covers 4 rows x 256 bytes (16 lanes x 16 bytes per
+// row), the workgroup 16 rows, eight such steps in flight per thread.  Column maxima: registers -> across the wave's four
+// row groups by shuffle -> across the four waves through LDS -> ONE atomicMax per column and workgroup (rows / 128 per
+// column in total: with one per 16 rows the 4096 hot addresses serialised the kernel, 53 us).  Row maxima: across the 16
+// lanes of a row -> one atomicMax per row and workgroup.
+template <typename T>
+__global__ __launch_bounds__(256) void k_rowcol_absmax8(const T *__restrict__ A, int64_t rows, int64_t cols,
+                                                       uint32_t *__restrict__ row_bits, uint32_t *__restrict__ col_bits) {
+    __shared__ float s_cm[4][128];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cg = lane & 15, rg = lane >> 4;                      // column group of 8, row within the wave's 4
+    const int64_t c0 = (int64_t)blockIdx.x * 128 + cg * 8;
+    const bool active = c0 < cols;
+    const int64_t r0 = (int64_t)blockIdx.y * 128 + wave * 4 + rg;  // + 16 * step
+    float x[8][8];
+#pragma unroll
+    for (int st = 0; st < 8; st++) {
+        const int64_t r = r0 + 16 * st;
+        if (active && r < rows) load8<T>(A, rows, cols, r, c0, true, x[st]);
+        else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) x[st][j] = 0.0f;
+        }
+    }
+    float cm[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) cm[j] = 0.0f;
+#pragma unroll
+    for (int st = 0; st < 8; st++) {
+        float rm = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const float a = fabsf(x[st][j]);
+            rm = fmaxf(rm, a);
+            cm[j] = fmaxf(cm[j], a);
+        }
+        if (row_bits) {
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) rm = fmaxf(rm, __shfl_xor(rm, off, 64));
+            const int64_t r = r0 + 16 * st;
+            if (cg == 0 && r < rows) atomicMax(row_bits + r, __float_as_uint(rm));
+        }
+    }
+    if (col_bits) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            cm[j] = fmaxf(cm[j], __shfl_xor(cm[j], 16, 64));
+            cm[j] = fmaxf(cm[j], __shfl_xor(cm[j], 32, 64));
+        }
+        if (rg == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) s_cm[wave][cg * 8 + j] = cm[j];
+        }
+        __syncthreads();
+        if (threadIdx.x < 128) {
+            const int64_t c = (int64_t)blockIdx.x * 128 + threadIdx.x;
+            const float m = fmaxf(fmaxf(s_cm[0][threadIdx.x], s_cm[1][threadIdx.x]), fmaxf(s_cm[2][threadIdx.x], s_cm[3][threadIdx.x]));
+            if (c < cols) atomicMax(col_bits + c, __float_as_uint(m));
+        }
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_double_quant8(const T *__restrict__ A, int64_t rows, int64_t cols,
+                                                      float *col_stats, float *row_stats,
+                                                      int8_t *__restrict__ out_col, int8_t *__restrict__ out_row,
+                                                      bool clamp_cols, bool clamp_rows) {
+    // clamp_rows / clamp_cols: the statistics were just computed as raw maxima; the reference's clamp(min=1e-8) is applied
+    // on read here, and written back by the first workgroup of each row / column group (readers clamp too, so either value
+    // they see gives the same scale) -- no separate clamp launch
+    const int64_t c0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (c0 >= cols) return;
+    const int64_t r0 = (int64_t)blockIdx.y * 8;
+    float x[8][8], rst[8];
+#pragma unroll
+    for (int rr = 0; rr < 8; rr++) {   // the eight rows' loads go out together
+        const int64_t r = r0 + rr;
+        if (r < rows) {
+            load8<T>(A, rows, cols, r, c0, true, x[rr]);
+            rst[rr] = clamp_rows ? fmaxf(row_stats[r], 1e-8f) : row_stats[r];   // caller-supplied statistics are used as given
+            if (clamp_rows && blockIdx.x == 0 && threadIdx.x == 0) row_stats[r] = rst[rr];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) x[rr][j] = 0.0f;
+            rst[rr] = 1.0f;
+        }
+    }
+    float cs[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const float c = clamp_cols ? fmaxf(col_stats[c0 + j], 1e-8f) : col_stats[c0 + j];
+        if (clamp_cols && blockIdx.y == 0) col_stats[c0 + j] = c;
+        cs[j] = rscale127(c);   // functional.py:858-861
+    }
+#pragma unroll
+    for (int rr = 0; rr < 8; rr++) {
+        const int64_t r = r0 + rr;
+        if (r >= rows) break;
+        const float rs = rscale127(rst[rr]);                             // functional.py:851-854
+        uint32_t rl = 0, rh = 0, cl = 0, ch = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            rl |= (uint32_t)(uint8_t)quant_i8(x[rr][j], rs) << (8 * j);
+            rh |= (uint32_t)(uint8_t)quant_i8(x[rr][4 + j], rs) << (8 * j);
+            cl |= (uint32_t)(uint8_t)quant_i8(x[rr][j], cs[j]) << (8 * j);
+            ch |= (uint32_t)(uint8_t)quant_i8(x[rr][4 + j], cs[4 + j]) << (8 * j);
+        }
+        *reinterpret_cast<u32x2 *>(out_row + r * cols + c0) = u32x2{rl, rh};
+        *reinterpret_cast<u32x2 *>(out_col + r * cols + c0) = u32x2{cl, ch};
+    }
+}
+
 // =====================================================================================
 // host launchers
 // =====================================================================================
@@ -985,6 +1107,20 @@ template <typename T>
 static int launch_double_quant(const void *A, int64_t rows, int64_t cols, int8_t *out_col, int8_t *out_row,
                                float *col_stats, float *row_stats, int col_given, int row_given, hipStream_t st) {
     const T *a = static_cast<const T *>(A);
+    if (cols % 8 == 0 && aligned16(A) && ((reinterpret_cast<uintptr_t>(out_col) | reinterpret_cast<uintptr_t>(out_row)) & 7) == 0 &&
+        (rows + 7) / 8 <= 65535) {
+        const unsigned gx = (unsigned)((cols / 8 + 255) / 256);
+        if (!row_given || !col_given) {
+            float *zr = row_given ? nullptr : row_stats, *zc = col_given ? nullptr : col_stats;
+            const int64_t nmax = rows > cols ? rows : cols;
+            hipLaunchKernelGGL(k_zero_stats2, dim3((unsigned)((nmax + 255) / 256)), dim3(256), 0, st, zr, rows, zc, cols);
+            hipLaunchKernelGGL(k_rowcol_absmax8<T>, dim3((unsigned)((cols + 127) / 128), (unsigned)((rows + 127) / 128)), dim3(256), 0, st, a,
+                               rows, cols, reinterpret_cast<uint32_t *>(zr), reinterpret_cast<uint32_t *>(zc));
+        }
+        hipLaunchKernelGGL(k_double_quant8<T>, dim3(gx, (unsigned)((rows + 7) / 8)), dim3(256), 0, st, a, rows, cols, col_stats,
+                           row_stats, out_col, out_row, !col_given, !row_given);
+        return check_launch("double_quant");
+    }
     if (!row_given) hipLaunchKernelGGL(k_row_absmax<T>, dim3((unsigned)rows), dim3(256), 0, st, a, rows, cols, row_stats);
     if (!col_given) {
         hipError_t e = hipMemsetAsync(col_stats, 0, sizeof(float) * cols, st);

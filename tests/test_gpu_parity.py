@@ -475,6 +475,27 @@ def test_g5_double_quant_bit_exact(golden):
         assert bits_equal(cs.cpu(), from_bits(npz[k + "col_stats"])) and bits_equal(rs.cpu(), from_bits(npz[k + "row_stats"]))
 
 
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("shape", [(1000, 2048), (37, 4104), (2051, 520), (64, 1001), (1, 8), (4096, 4096)])
+def test_double_quant_vector_and_scalar_forms_bit_exact(dt, shape):
+    """double_quant (functional.py:814-863): the vector form (cols % 8 == 0: one statistics pass with atomic maxima, one
+    quantise pass) and the scalar form, with computed and with caller-supplied statistics: both int8 copies and both
+    statistics equal the oracle's."""
+    x = synthetic.normal(shape, dt, seed=53 + shape[1] % 89)
+    x[0, 0] = 0.0
+    want = oracle.double_quant(x)
+    got = bnb.double_quant(x.to(DEV))
+    assert n_mismatch(got[0].cpu(), want[0]) == 0 and n_mismatch(got[1].cpu(), want[1]) == 0
+    assert bits_equal(got[2].cpu(), want[2]) and bits_equal(got[3].cpu(), want[3]) and got[4] is None
+    cs = (synthetic.normal((shape[1],), torch.float32, seed=7).abs() + 0.25)
+    rs = (synthetic.normal((shape[0],), torch.float32, seed=8).abs() + 0.25)
+    for kw in (dict(col_stats=cs), dict(row_stats=rs), dict(col_stats=cs, row_stats=rs)):
+        want = oracle.double_quant(x, **kw)
+        got = bnb.double_quant(x.to(DEV), **{k: v.to(DEV) for k, v in kw.items()})
+        assert n_mismatch(got[0].cpu(), want[0]) == 0 and n_mismatch(got[1].cpu(), want[1]) == 0, kw.keys()
+        assert bits_equal(got[2].cpu(), want[2]) and bits_equal(got[3].cpu(), want[3]), kw.keys()
+
+
 def test_g5_matmul_int8_and_linear8bit(golden):
     npz = golden.npz("g5_int8.npz")
     for c in [c for c in golden.manifest["g5"] if c["kind"] == "matmul_int8"]:

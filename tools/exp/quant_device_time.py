@@ -29,3 +29,6 @@ for dt in (torch.float16, torch.bfloat16):
     for name, fn in (("quantize_nf4", lambda: bnb.quantize_nf4(W)), ("quantize_nf4 + double quant", lambda: bnb.quantize_nf4(W, compress_statistics=True)),
                      ("quantize_rowwise", lambda: bnb.quantize_rowwise(W)), ("quantize_fp8_e4m3", lambda: bnb.quantize_fp8_e4m3(W))):
         print("%s %s: %.2f us" % (dt, name, graphed(fn)), flush=True)
+for dt in (torch.float16,):
+    W = torch.randn(4096, 4096, device=dev).to(dt)
+    print("%s double_quant (row + column statistics, both int8 copies): %.2f us" % (dt, graphed(lambda: bnb.double_quant(W))), flush=True)
