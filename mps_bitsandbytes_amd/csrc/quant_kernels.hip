@@ -651,8 +651,16 @@ __global__ __launch_bounds__(256) void k_quantize_fp8(const T *__restrict__ A, i
     if (nan > 0.0f) s = __builtin_bit_cast(float, 0x7FC00000u);
     if (threadIdx.x == 0) scales[r] = s;
     uint8_t *orow = out + r * cols;
+    // v / s, a true division in the reference: the row's scale is shared, so the reciprocal part of the IEEE expansion is
+    // computed once (SharedDiv above) while v_div_scale would be the identity -- s in [2^-20, 2^60] (|v| <= 448 s: no
+    // overflow, no denormal quotient from a normal numerator) and |v| >= 2^-90 or v == 0 (a tinier numerator would be
+    // rescaled by the expansion and decides the sign byte of a flushed result: those lanes keep the plain division)
+    const bool shared = s >= 0x1p-20f && s <= 0x1p60f;
+    const SharedDiv sd = shared_div(s);
     auto enc = [&](float v) {
-        float n = v / s;                                   // true division, as the reference
+        float n;
+        if (shared && (fabsf(v) >= 0x1p-90f || v == 0.0f)) n = sd(v);
+        else n = v / s;                                    // true division, as the reference
         n = (n < -448.0f) ? -448.0f : ((n > 448.0f) ? 448.0f : n);   // clamp keeps NaN
         return float_to_fp8_e4m3(n);
     };

@@ -191,9 +191,8 @@ def test_fp8_quantize_full_size_vs_oracle():
 def test_fp8_quantize_dynamic_range_bit_exact(dt, emin, emax):
     """v / scale is a true division in the reference (functional.py:1086-1104) and the encoder reads the exponent off log2.
     Rows scaled by 2^e over the dtype's range, numerators below 2^-90 of both signs, signed zeros and exact powers of two
-    planted inside normal rows: bytes and scales equal the oracle's.  (A shared-reciprocal division as in quantize_4bit was
-    tried here and is bit-exact on this test, but the kernel is bound by the ~60 VALU of the encoder, not the division:
-    32.5 us at 4096^2 either way.)"""
+    planted inside normal rows: bytes and scales equal the oracle's.  Pins the integer form of the encoder (exponent / mantissa
+    fields instead of log2 / division: common.h float_to_fp8_e4m3) and the shared-reciprocal division of the kernel."""
     rows, cols = 663, 1024
     x = synthetic.normal((rows, cols), torch.float32, seed=941)
     e = torch.arange(rows) % (emax - emin + 1) + emin
