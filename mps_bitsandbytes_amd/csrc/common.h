@@ -154,6 +154,18 @@ __device__ __forceinline__ uint32_t float_to_fp8_e4m3(float v) {
     return sign | ((uint32_t)biased << 3) | mb;
 }
 
+// Optional second term of an int8 GEMM epilogue (OutlierAwareLinear.forward, nn/outlier_aware.py:141-143, :110-111):
+//   out = RNE(RNE(RNE(acc * sA/127 * sB/127) + RNE(X[:, oidx] . ow^T)) + bias)
+// x == nullptr: no outlier term; bias == nullptr: no bias; both null: the plain matmul_int8 epilogue.
+struct OutlierEpilogue {
+    const void *x;        // [M, ldx] outlier activations (compact, zero padded) in the output dtype (16-bit)
+    int64_t ldx;          // = 16 * ceil(n_out / 16)
+    const int64_t *oidx;  // [n_out]
+    int64_t n_out;
+    const void *ow;       // [N, n_out] outlier weights in the output dtype
+    const void *bias;     // [N] or nullptr
+};
+
 template <int WF> __device__ __forceinline__ float w8_row_scale(float s) { return WF == W8_INT8 ? s / 127.0f : s; }
 template <int WF> __device__ __forceinline__ float w8_decode(uint32_t byte) {   // byte in bits 0..7
     if constexpr (WF == W8_INT8) return (float)(int)(int8_t)byte;

@@ -62,12 +62,17 @@ template <int FM> struct GdPlan {
 // [N, 2 ldw bytes] -- a row of 2K int8 moves and lands exactly like a row of K 16-bit values, and a lane's 16 bytes of a k32
 // slice are the 16 consecutive int8 of a k64 slice of v_mfma_i32_16x16x64_i8 -- T is the 16-bit container type, K and ldw count
 // byte PAIRS.  Accumulators hold the int32 sums (as raw bits); epilogue: float(sum) * (sA[m] / 127) * (sB[n] / 127), cast.
-template <typename T, bool SPLITK, int FM = 8, bool I8 = false>
+// OUTL (with I8, 16-bit outputs): the epilogue adds OutlierAwareLinear's second term and bias (OutlierEpilogue, common.h) with
+// the reference's rounding chain -- per 16 x 16 output fragment ONE 16 x 16 x 32 MFMA of the 16-bit outlier weights [n, <= 32]
+// and the row's compact outlier activations [m, <= 32] (zero padded), operands straight from global / L2.  OUTL = 1: f16 outputs,
+// 2: bf16 outputs (the rounding chain is compiled for one type: every instruction of this epilogue runs 256 times per lane).
+template <typename T, bool SPLITK, int FM = 8, bool I8 = false, int OUTL = 0>
 __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, const T *__restrict__ Wd, const T *__restrict__ bias,
                                                        void *__restrict__ out_v, int out_dtype, float *__restrict__ partial,
                                                        int64_t M, int64_t N, int64_t K, int64_t ldw, int64_t k_per_slice,
-                                                       const float *__restrict__ sA, const float *__restrict__ sB) {
+                                                       const float *__restrict__ sA, const float *__restrict__ sB, OutlierEpilogue ep) {
     static_assert(!(I8 && SPLITK), "the int8 form is not split");
+    static_assert(OUTL == 0 || I8, "the outlier epilogue belongs to the int8 form");
     using Frag = typename Mfma16<T>::frag;
     using Plan = GdPlan<FM>;
     constexpr int TM = 32 * FM;                 // rows of A per tile: two waves of 16 FM
@@ -299,12 +304,81 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, 
     char *wave_lds = smem + wave * 64 * ROWB;
     uint16_t *out = static_cast<uint16_t *>(out_v);
     const bool vec_ok = (N % 8 == 0) && ((reinterpret_cast<uintptr_t>(out_v) & 15) == 0);
+    const bool with_outl = OUTL != 0 && ep.x != nullptr && ep.n_out > 0;
+    const bool ow_vec = OUTL != 0 && (ep.n_out % 8 == 0) && ((reinterpret_cast<uintptr_t>(ep.ow) & 15) == 0);
+    using OutlT = std::conditional_t<OUTL == 1, f16_t, bf16_t>;
+    auto rne = [&](float x) { return to_f32(from_f32<OutlT>(x)); };   // round to the output dtype and back
+    // OUTL operands, all requested here in one burst (inside the fragment loops each load would cost a full memory latency:
+    // the accumulator reads below are ordered asm): per 16-column group f the outlier weights of row n = 16 f + er16 (8 per
+    // lane at outlier index 8 efq) and the four bias values of the lane's columns; per 16-row group the compact activations
+    u32x4 wfr_all[OUTL ? 8 : 1];
+    u32x2 bias_all[OUTL ? 8 : 1];
+    u32x4 xfr_all[OUTL ? FM : 1];
+    if constexpr (OUTL) {
+#pragma unroll
+        for (int f = 0; f < 8; f++) {
+            wfr_all[f] = u32x4{0u, 0u, 0u, 0u};
+            bias_all[f] = u32x2{0u, 0u};
+            if (with_outl) {
+                const uint16_t *ow = static_cast<const uint16_t *>(ep.ow);
+                int64_t n = n_base + 16 * f + er16;
+                n = n < N ? n : N - 1;
+                const int64_t j0 = 8 * efq;
+                if (ow_vec && j0 + 8 <= ep.n_out) wfr_all[f] = *reinterpret_cast<const u32x4 *>(ow + n * ep.n_out + j0);
+                else {
+                    uint32_t t[8];
+#pragma unroll
+                    for (int e = 0; e < 8; e++) t[e] = (j0 + e < ep.n_out) ? (uint32_t)ow[n * ep.n_out + j0 + e] : 0u;
+                    wfr_all[f] = u32x4{t[0] | (t[1] << 16), t[2] | (t[3] << 16), t[4] | (t[5] << 16), t[6] | (t[7] << 16)};
+                }
+            }
+            if (ep.bias != nullptr) {
+                const uint16_t *bp = static_cast<const uint16_t *>(ep.bias);
+                const int64_t n = n_base + 16 * f + 4 * efq;
+                if (n + 4 <= N && (reinterpret_cast<uintptr_t>(bp + n) & 7) == 0) bias_all[f] = *reinterpret_cast<const u32x2 *>(bp + n);
+                else {
+                    uint32_t t[4];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) t[e] = bp[n + e < N ? n + e : N - 1];
+                    bias_all[f] = u32x2{t[0] | (t[1] << 16), t[2] | (t[3] << 16)};
+                }
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < FM; g++) {
+            xfr_all[g] = u32x4{0u, 0u, 0u, 0u};
+            if (with_outl) {
+                const uint16_t *xx = static_cast<const uint16_t *>(ep.x);
+                int64_t m = m0 + wm * 16 * FM + 16 * g + er16;
+                m = m < M ? m : M - 1;
+                if (8 * efq < ep.ldx) xfr_all[g] = *reinterpret_cast<const u32x4 *>(xx + m * ep.ldx + 8 * efq);
+            }
+        }
+    }
     gd_static_for<FM / 4>([&](auto hh) {
         constexpr int H = decltype(hh)::value;
         const int64_t m_base = m0 + wm * 16 * FM + 64 * H;
+        float sa[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // I8: the four row groups' scales
+        if constexpr (I8) {
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int64_t m = m_base + 16 * g + er16;
+                sa[g] = sA[m < M ? m : M - 1] / 127.0f;
+            }
+        }
 #pragma unroll
         for (int f = 0; f < 8; f++) {
             const int nl = 16 * f + 4 * efq;
+            float bb[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if constexpr (OUTL) {
+                if (ep.bias != nullptr) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const uint32_t hb = bias_all[f][e >> 1] >> (16 * (e & 1));
+                        bb[e] = unpack_lo<OutlT>(hb);
+                    }
+                }
+            }
             float bv[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // I8: the four column scales
             if (I8 || bias != nullptr) {
 #pragma unroll
@@ -322,14 +396,27 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, 
                     float sv;
                     asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(sv) : "a"(acc[f][4 * H + g][e]));
                     if constexpr (I8) {
-                        const int64_t m = m_base + 16 * g + er16;
-                        v[e] = (float)__builtin_bit_cast(int, sv) * (sA[m < M ? m : M - 1] / 127.0f) * bv[e];
+                        v[e] = (float)__builtin_bit_cast(int, sv) * sa[g] * bv[e];
                     } else {
                         v[e] = to_f32(from_f32<T>(sv + bv[e]));
                     }
                 }
+                if constexpr (OUTL) {
+                    if (with_outl) {
+                        f32x4 o = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                        using OFrag = typename Mfma16<OutlT>::frag;
+                        o = Mfma16<OutlT>::run(__builtin_bit_cast(OFrag, wfr_all[f]), __builtin_bit_cast(OFrag, xfr_all[4 * H + g]), o);
+#pragma unroll
+                        for (int e = 0; e < 4; e++) v[e] = rne(rne(v[e]) + rne(o[e]));
+                    }
+                    if (ep.bias != nullptr) {   // (v is in the output type's grid after the outlier term: rounded once here otherwise)
+#pragma unroll
+                        for (int e = 0; e < 4; e++) v[e] = rne((with_outl ? v[e] : rne(v[e])) + bb[e]);
+                    }
+                }
                 u32x2 pk;
-                if (out_dtype == MBNB_F16) pk = u32x2{pack2<f16_t>(v[0], v[1]), pack2<f16_t>(v[2], v[3])};
+                if constexpr (OUTL != 0) pk = u32x2{pack2<OutlT>(v[0], v[1]), pack2<OutlT>(v[2], v[3])};
+                else if (out_dtype == MBNB_F16) pk = u32x2{pack2<f16_t>(v[0], v[1]), pack2<f16_t>(v[2], v[3])};
                 else pk = u32x2{pack2<bf16_t>(v[0], v[1]), pack2<bf16_t>(v[2], v[3])};
                 *reinterpret_cast<u32x2 *>(wave_lds + (16 * g + er16) * ROWB + nl * 2) = pk;
             }

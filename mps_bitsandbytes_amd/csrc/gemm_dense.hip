@@ -71,7 +71,7 @@ static int launch_gemm_dense_fm(const T *x, const T *wd, const T *bias, void *ou
         auto kern = k_gemm_dense<T, false, FM>;
         if (int rc = ensure_dyn_lds(reinterpret_cast<const void *>(kern), GD_LDS, "matmul_4bit(dense)")) return rc;
         hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), GD_LDS, st, x, wd, bias, out, out_dtype, static_cast<float *>(nullptr),
-                           M, N, K, ldw, K, static_cast<const float *>(nullptr), static_cast<const float *>(nullptr));
+                           M, N, K, ldw, K, static_cast<const float *>(nullptr), static_cast<const float *>(nullptr), OutlierEpilogue{});
         return check_launch("matmul_4bit(dense)");
     }
     auto kern = k_gemm_dense<T, true, FM>;
@@ -79,7 +79,7 @@ static int launch_gemm_dense_fm(const T *x, const T *wd, const T *bias, void *ou
     const int64_t kps = gemm_dense_k_per_slice(K, slices);
     const int64_t used = (K + kps - 1) / kps;    // no empty slice
     hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * used)), dim3(256), GD_LDS, st, x, wd, bias, out, out_dtype, partial, M, N, K, ldw,
-                       kps, static_cast<const float *>(nullptr), static_cast<const float *>(nullptr));
+                       kps, static_cast<const float *>(nullptr), static_cast<const float *>(nullptr), OutlierEpilogue{});
     if (int rc = check_launch("matmul_4bit(dense split-K)")) return rc;
     const int64_t groups = M * ((N + 3) / 4);
     const unsigned blocks = (unsigned)((groups + 255) / 256);
@@ -164,14 +164,26 @@ int linear8_dense_path(const void *X, int dtype, int64_t M, int64_t K, const voi
 bool gemm_i8_dense_shape(int64_t M, int64_t N, int64_t K) {
     return (K % 128 == 0) && K >= 256 && 256 * K < ((int64_t)1 << 31) && ((M + 255) / 256) * ((N + 255) / 256) >= 96;
 }
+// ep != nullptr (OutlierAwareLinear): outlier term and bias in the epilogue; the caller checks gemm_i8_dense_outlier_ok first.
+bool gemm_i8_dense_outlier_ok(const OutlierEpilogue &ep, int out_dtype) {
+    return out_dtype != MBNB_F32 && (ep.x == nullptr || ep.n_out == 0 || (ep.ldx <= 32 && ep.ldx % 16 == 0 && (reinterpret_cast<uintptr_t>(ep.x) & 15) == 0));
+}
 int launch_gemm_i8_dense(const int8_t *A, const int8_t *Bt, const float *sA, const float *sB, int64_t M, int64_t N, int64_t K,
-                         int out_dtype, void *out, hipStream_t st) {
+                         int out_dtype, void *out, hipStream_t st, const OutlierEpilogue *ep) {
+    const int64_t tiles = ((M + 255) / 256) * ((N + 255) / 256);
+    if (ep != nullptr) {
+        auto kern = out_dtype == MBNB_F16 ? k_gemm_dense<bf16_t, false, 8, true, 1> : k_gemm_dense<bf16_t, false, 8, true, 2>;
+        if (int rc = ensure_dyn_lds(reinterpret_cast<const void *>(kern), GD_LDS, "matmul_int8(dense+outliers)")) return rc;
+        hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), GD_LDS, st, reinterpret_cast<const bf16_t *>(A),
+                           reinterpret_cast<const bf16_t *>(Bt), static_cast<const bf16_t *>(nullptr), out, out_dtype,
+                           static_cast<float *>(nullptr), M, N, K / 2, K / 2, K / 2, sA, sB, *ep);
+        return check_launch("matmul_int8(dense+outliers)");
+    }
     auto kern = k_gemm_dense<bf16_t, false, 8, true>;
     if (int rc = ensure_dyn_lds(reinterpret_cast<const void *>(kern), GD_LDS, "matmul_int8(dense)")) return rc;
-    const int64_t tiles = ((M + 255) / 256) * ((N + 255) / 256);
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), GD_LDS, st, reinterpret_cast<const bf16_t *>(A),
                        reinterpret_cast<const bf16_t *>(Bt), static_cast<const bf16_t *>(nullptr), out, out_dtype,
-                       static_cast<float *>(nullptr), M, N, K / 2, K / 2, K / 2, sA, sB);
+                       static_cast<float *>(nullptr), M, N, K / 2, K / 2, K / 2, sA, sB, OutlierEpilogue{});
     return check_launch("matmul_int8(dense)");
 }
 

@@ -191,18 +191,6 @@ __global__ __launch_bounds__(256, 2) void k_gemm_i8(const int8_t *__restrict__ A
 // with BOTH operands arriving by LDS-DMA (no decode): 8 x 1 KiB pieces per wave and k-step, issued one
 // per MFMA right after the barrier that frees the stage; one barrier per k-step between MFMA groups 2
 // and 3, next group's fragments read before the current group's MFMAs.  Requires K % 128 == 0.
-// Optional second term of the epilogue (OutlierAwareLinear.forward, nn/outlier_aware.py:141-143, :110-111):
-//   out = RNE(RNE(RNE(acc * sA/127 * sB/127) + RNE(X[:, oidx] . ow^T)) + bias)
-// x == nullptr: no outlier term; bias == nullptr: no bias; both null: the plain matmul_int8 epilogue.
-struct OutlierEpilogue {
-    const void *x;        // [M, ldx] outlier activations (compact, zero padded) in the output dtype (16-bit)
-    int64_t ldx;          // = 16 * ceil(n_out / 16)
-    const int64_t *oidx;  // [n_out]
-    int64_t n_out;
-    const void *ow;       // [N, n_out] outlier weights in the output dtype
-    const void *bias;     // [N] or nullptr
-};
-
 // Epilogue of the 256 x 256 int8 kernels (wave tile 128 n x 64 m, acc[i][j][4g+e] = out[m0 + 64 wm + 32 j + fr][n0 + 128 wn +
 // 32 i + 8 g + 4 fh + e]): scales, optional outlier term and bias (OutlierEpilogue), rounding chain of the reference.
 template <typename OutT>
@@ -475,7 +463,13 @@ __global__ __launch_bounds__(256) void k_matmul_i8_generic_nt(const int8_t *__re
     out[i] = from_f32<OutT>((float)acc * (sA[m] / 127.0f) * (sB[n] / 127.0f));
 }
 
-// `ep` (may be nullptr): outlier / bias epilogue.  It is applied only by the 256 x 256 kernel with a 16-bit output;
+// gemm_dense.hip: the four-wave pipeline on int8 operands (ep: OutlierAwareLinear's second term and bias in its epilogue)
+bool gemm_i8_dense_shape(int64_t M, int64_t N, int64_t K);
+bool gemm_i8_dense_outlier_ok(const OutlierEpilogue &ep, int out_dtype);
+int launch_gemm_i8_dense(const int8_t *, const int8_t *, const float *, const float *, int64_t, int64_t, int64_t, int, void *, hipStream_t,
+                         const OutlierEpilogue *ep = nullptr);
+
+// `ep` (may be nullptr): outlier / bias epilogue.  It is applied only by the 256 x 256 kernels with a 16-bit output;
 // *ep_done tells the caller whether it was (otherwise the caller runs k_outlier_add afterwards).
 int matmul_int8_nt_dispatch(const int8_t *A, const int8_t *Bt, const float *sA, const float *sB, int64_t M, int64_t N,
                             int64_t K, int out_dtype, void *out, hipStream_t st, const OutlierEpilogue *ep = nullptr,
@@ -491,6 +485,14 @@ int matmul_int8_nt_dispatch(const int8_t *A, const int8_t *Bt, const float *sA, 
         }
         set_kernel_name("i8_generic");
         return check_launch("matmul_int8(generic nt)");
+    }
+    // OutlierAwareLinear with at most 32 outlier columns: the four-wave pipeline of gemm_dense.h, outlier term and bias in
+    // its epilogue (one 16 x 16 x 32 MFMA per output fragment)
+    if (ep != nullptr && gemm_i8_dense_shape(M, N, K) && gemm_i8_dense_outlier_ok(*ep, out_dtype)) {
+        const int rc = launch_gemm_i8_dense(A, Bt, sA, sB, M, N, K, out_dtype, out, st, ep);
+        if (ep_done) *ep_done = true;
+        set_kernel_name("i8_dense+outliers");
+        return rc;
     }
     if ((K % 128 == 0) && ((M + 255) / 256) * ((N + 255) / 256) >= 96) {
         const int64_t tiles256 = ((M + 255) / 256) * ((N + 255) / 256);
@@ -536,8 +538,6 @@ int matmul_int8_nt_dispatch(const int8_t *A, const int8_t *Bt, const float *sA, 
 // matmul_int8 reads B as the reference passes it, [K, N] row-major.  Large aligned problems go straight to the 256 x 256
 // kernel's transposing-read form (no workspace); everything else is first re-laid out K-contiguous into the caller's
 // workspace (N * K bytes) or, without one, served by the generic kernel.
-bool gemm_i8_dense_shape(int64_t M, int64_t N, int64_t K);
-int launch_gemm_i8_dense(const int8_t *, const int8_t *, const float *, const float *, int64_t, int64_t, int64_t, int, void *, hipStream_t);
 
 // large problems with a caller workspace: B transposed once into it, then the four-wave pipeline of gemm_dense.h on int8
 static bool matmul_int8_dense(int64_t M, int64_t N, int64_t K) {

@@ -14,14 +14,6 @@ namespace mbnb {
 int check_launch(const char *what);
 void set_error(const char *fmt, ...);
 void set_kernel_name(const char *name);
-struct OutlierEpilogue {   // int8_kernels.hip: optional outlier / bias term of the 256 x 256 int8 kernel's epilogue
-    const void *x;
-    int64_t ldx;
-    const int64_t *oidx;
-    int64_t n_out;
-    const void *ow;
-    const void *bias;
-};
 int matmul_int8_nt_dispatch(const int8_t *A, const int8_t *Bt, const float *sA, const float *sB, int64_t M, int64_t N,
                             int64_t K, int out_dtype, void *out, hipStream_t st, const OutlierEpilogue *ep, bool *ep_done);
 

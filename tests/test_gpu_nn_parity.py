@@ -130,11 +130,17 @@ def test_outlier_linear_golden(g6):
 
 @pytest.mark.parametrize("M,K,N,dt,n_out,bias", [(512, 4096, 4096, torch.float16, 12, True), (300, 1024, 777, torch.bfloat16, 0, True),
                                                   (64, 200, 96, torch.float16, 3, False), (2048, 4096, 4096, torch.bfloat16, 40, False),
-                                                  (2560, 512, 2560, torch.float16, 21, True), (2600, 256, 2500, torch.bfloat16, 64, True)])
+                                                  (2560, 512, 2560, torch.float16, 21, True), (2600, 256, 2500, torch.bfloat16, 64, True),
+                                                  (4096, 4096, 4096, torch.bfloat16, 16, True), (2560, 512, 2560, torch.bfloat16, 0, True),
+                                                  (2500, 384, 2608, torch.float16, 32, False), (2560, 640, 2568, torch.bfloat16, 7, True)])
 def test_outlier_linear_vs_oracle(M, K, N, dt, n_out, bias):
     """MFMA-sized shapes (256^2 and 128^2 int8 kernels), ragged K (generic kernel), with / without outliers and bias; on the
-    256^2 kernel the outlier columns ride in the epilogue in chunks of 16 (12, 21, 40 and 64 columns: one to four chunks,
-    ragged last chunk, weight rows not 16-byte aligned at 21)."""
+    eight-wave 256^2 kernel the outlier columns ride in the epilogue in chunks of 16 (40 and 64 columns: three / four chunks,
+    ragged last chunk); with at most 32 of them on >= 96 tiles the four-wave kernel of gemm_dense.h carries them (21: weight
+    rows not 16-byte aligned; 0 + bias; ragged M / N; the 4096^3 bench shape)."""
+    want = None
+    if K % 128 == 0 and K >= 256 and ((M + 255) // 256) * ((N + 255) // 256) >= 96 and (n_out > 0 or bias):
+        want = "i8_dense+outliers" if n_out <= 32 else "i8_mfma256"
     W = synthetic.normal((N, K), torch.float32, seed=821, std=0.05)
     oidx = torch.from_numpy(np.sort((synthetic.uniform_u64(4 * n_out + 1, seed=822) % np.uint64(K)).astype(np.int64))).unique()[:n_out]
     W[:, oidx] *= 30.0
@@ -146,7 +152,9 @@ def test_outlier_linear_vs_oracle(M, K, N, dt, n_out, bias):
     b = synthetic.normal((N,), dt, seed=823) if bias else None
     x = synthetic.normal((M, K), dt, seed=824)
     y = bnb.outlier_linear(x.to(DEV), q.to(DEV), s.to(DEV), oidx.to(DEV), ow.to(DEV), None if b is None else b.to(DEV), dt)
-    rows = torch.arange(0, M, max(1, M // 64))[:64]           # rows are independent: a row sample bounds the oracle's time
+    if want is not None:
+        assert _native.last_kernel() == want, _native.last_kernel()
+    rows = torch.cat([torch.arange(0, M, max(1, M // 60))[:60], torch.arange(M - 4, M)])   # incl. the ragged last tile           # rows are independent: a row sample bounds the oracle's time
     ref = oracle.outlier_linear(x[rows], q, s, oidx, ow, b)
     err = rel_fro(y.cpu()[rows], ref)
     assert err <= OA_TOL[dt], err
