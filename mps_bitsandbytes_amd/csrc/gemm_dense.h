@@ -28,6 +28,7 @@
 // on every shape tested (tests/test_gpu_parity.py asserts equality with the fused kernel, and parity with the oracle).
 #pragma once
 #include "gemm256.h"
+#include <type_traits>
 #include <utility>
 
 namespace mbnb {
@@ -304,6 +305,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, 
     char *wave_lds = smem + wave * 64 * ROWB;
     uint16_t *out = static_cast<uint16_t *>(out_v);
     const bool vec_ok = (N % 8 == 0) && ((reinterpret_cast<uintptr_t>(out_v) & 15) == 0);
+    const bool same_out = !I8 && out_dtype == (std::is_same_v<T, f16_t> ? MBNB_F16 : MBNB_BF16);
     const bool with_outl = OUTL != 0 && ep.x != nullptr && ep.n_out > 0;
     const bool ow_vec = OUTL != 0 && (ep.n_out % 8 == 0) && ((reinterpret_cast<uintptr_t>(ep.ow) & 15) == 0);
     using OutlT = std::conditional_t<OUTL == 1, f16_t, bf16_t>;
@@ -395,13 +397,18 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, 
                 for (int e = 0; e < 4; e++) {
                     float sv;
                     asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(sv) : "a"(acc[f][4 * H + g][e]));
-                    if constexpr (I8) {
-                        v[e] = (float)__builtin_bit_cast(int, sv) * sa[g] * bv[e];
-                    } else {
-                        v[e] = to_f32(from_f32<T>(sv + bv[e]));
+                    if constexpr (I8) v[e] = (float)__builtin_bit_cast(int, sv) * sa[g] * bv[e];
+                    else v[e] = sv + bv[e];
+                }
+                if constexpr (!I8) {
+                    // output type != weight type: round to the weight type first (the reference computes in it, then casts);
+                    // same type: the pack below is this very rounding (every instruction here runs 256 x per lane)
+                    if (!same_out) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) v[e] = to_f32(from_f32<T>(v[e]));
                     }
                 }
-                if constexpr (OUTL) {
+                if constexpr (OUTL != 0) {
                     if (with_outl) {
                         f32x4 o = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
                         using OFrag = typename Mfma16<OutlT>::frag;
