@@ -357,6 +357,28 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, 
             }
         }
     }
+    // I8: the lane's 8 x 4 column scales sB / 127, requested once for both halves (in the fragment loop they cost a memory
+    // latency and four IEEE divisions per column group and half)
+    float bv_all[I8 ? 8 : 1][4];
+    if constexpr (I8) {
+        const bool sb_vec = (reinterpret_cast<uintptr_t>(sB) & 15) == 0;
+#pragma unroll
+        for (int f = 0; f < 8; f++) {
+            const int64_t n = n_base + 16 * f + 4 * efq;
+            f32x4 t;
+            if (sb_vec && n + 4 <= N) t = *reinterpret_cast<const f32x4 *>(sB + n);
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; e++) t[e] = sB[n + e < N ? n + e : N - 1];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; e++) bv_all[f][e] = t[e] / 127.0f;
+        }
+    }
+    // WO / WB: outlier term / OutlierEpilogue bias present -- compile-time inside the fragment loops (as run-time tests they
+    // became four branches per fragment)
+    auto epilogue16 = [&](auto wo_t, auto wb_t) {
+    constexpr bool WO = decltype(wo_t)::value, WB = decltype(wb_t)::value;
     gd_static_for<FM / 4>([&](auto hh) {
         constexpr int H = decltype(hh)::value;
         const int64_t m_base = m0 + wm * 16 * FM + 64 * H;
@@ -372,22 +394,22 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, 
         for (int f = 0; f < 8; f++) {
             const int nl = 16 * f + 4 * efq;
             float bb[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            if constexpr (OUTL) {
-                if (ep.bias != nullptr) {
+            if constexpr (WB) {
 #pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        const uint32_t hb = bias_all[f][e >> 1] >> (16 * (e & 1));
-                        bb[e] = unpack_lo<OutlT>(hb);
-                    }
+                for (int e = 0; e < 4; e++) {
+                    const uint32_t hb = bias_all[f][e >> 1] >> (16 * (e & 1));
+                    bb[e] = unpack_lo<OutlT>(hb);
                 }
             }
             float bv[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // I8: the four column scales
-            if (I8 || bias != nullptr) {
+            if constexpr (I8) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) bv[e] = bv_all[f][e];
+            } else if (bias != nullptr) {
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
                     const int64_t n = n_base + nl + e;
-                    if constexpr (I8) bv[e] = sB[n < N ? n : N - 1] / 127.0f;
-                    else bv[e] = to_f32(bias[n < N ? n : N - 1]);
+                    bv[e] = to_f32(bias[n < N ? n : N - 1]);
                 }
             }
 #pragma unroll
@@ -409,16 +431,16 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, 
                     }
                 }
                 if constexpr (OUTL != 0) {
-                    if (with_outl) {
+                    if constexpr (WO) {
                         f32x4 o = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
                         using OFrag = typename Mfma16<OutlT>::frag;
                         o = Mfma16<OutlT>::run(__builtin_bit_cast(OFrag, wfr_all[f]), __builtin_bit_cast(OFrag, xfr_all[4 * H + g]), o);
 #pragma unroll
                         for (int e = 0; e < 4; e++) v[e] = rne(rne(v[e]) + rne(o[e]));
                     }
-                    if (ep.bias != nullptr) {   // (v is in the output type's grid after the outlier term: rounded once here otherwise)
+                    if constexpr (WB) {   // (v is in the output type's grid after the outlier term: rounded once here otherwise)
 #pragma unroll
-                        for (int e = 0; e < 4; e++) v[e] = rne((with_outl ? v[e] : rne(v[e])) + bb[e]);
+                        for (int e = 0; e < 4; e++) v[e] = rne((WO ? v[e] : rne(v[e])) + bb[e]);
                     }
                 }
                 u32x2 pk;
@@ -459,6 +481,20 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, 
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this half's staging reads are done before the next half's writes
     });
+    };
+    using Yes = std::true_type;
+    using No = std::false_type;
+    if constexpr (OUTL != 0) {
+        if (with_outl) {
+            if (ep.bias != nullptr) epilogue16(Yes{}, Yes{});
+            else epilogue16(Yes{}, No{});
+        } else {
+            if (ep.bias != nullptr) epilogue16(No{}, Yes{});
+            else epilogue16(No{}, No{});
+        }
+    } else {
+        epilogue16(No{}, No{});
+    }
 }
 
 }  // namespace mbnb
