@@ -314,8 +314,24 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, 
     // the accumulator reads below are ordered asm): per 16-column group f the outlier weights of row n = 16 f + er16 (8 per
     // lane at outlier index 8 efq) and the four bias values of the lane's columns; per 16-row group the compact activations
     u32x4 wfr_all[OUTL ? 8 : 1];
-    u32x2 bias_all[OUTL ? 8 : 1];
+    u32x2 bias_all[(OUTL || !I8) ? 8 : 1];   // 16-bit forms: the kernel's own bias (in T) travels the same way
     u32x4 xfr_all[OUTL ? FM : 1];
+    if constexpr (!I8) {
+        if (bias != nullptr) {
+            const uint16_t *bp = reinterpret_cast<const uint16_t *>(bias);
+#pragma unroll
+            for (int f = 0; f < 8; f++) {
+                const int64_t n = n_base + 16 * f + 4 * efq;
+                if (n + 4 <= N && (reinterpret_cast<uintptr_t>(bp + n) & 7) == 0) bias_all[f] = *reinterpret_cast<const u32x2 *>(bp + n);
+                else {
+                    uint32_t t[4];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) t[e] = bp[n + e < N ? n + e : N - 1];
+                    bias_all[f] = u32x2{t[0] | (t[1] << 16), t[2] | (t[3] << 16)};
+                }
+            }
+        }
+    }
     if constexpr (OUTL) {
 #pragma unroll
         for (int f = 0; f < 8; f++) {
@@ -375,8 +391,8 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, 
             for (int e = 0; e < 4; e++) bv_all[f][e] = t[e] / 127.0f;
         }
     }
-    // WO / WB: outlier term / OutlierEpilogue bias present -- compile-time inside the fragment loops (as run-time tests they
-    // became four branches per fragment)
+    // WO / WB: outlier term / bias (OutlierEpilogue's, or the 16-bit kernel's own) present -- compile-time inside the fragment
+    // loops (as run-time tests they became four branches per fragment; bias loads in the loops cost a memory latency each)
     auto epilogue16 = [&](auto wo_t, auto wb_t) {
     constexpr bool WO = decltype(wo_t)::value, WB = decltype(wb_t)::value;
     gd_static_for<FM / 4>([&](auto hh) {
@@ -394,7 +410,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, 
         for (int f = 0; f < 8; f++) {
             const int nl = 16 * f + 4 * efq;
             float bb[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            if constexpr (WB) {
+            if constexpr (WB && I8) {
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
                     const uint32_t hb = bias_all[f][e >> 1] >> (16 * (e & 1));
@@ -405,12 +421,9 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, 
             if constexpr (I8) {
 #pragma unroll
                 for (int e = 0; e < 4; e++) bv[e] = bv_all[f][e];
-            } else if (bias != nullptr) {
+            } else if constexpr (WB) {
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const int64_t n = n_base + nl + e;
-                    bv[e] = to_f32(bias[n < N ? n : N - 1]);
-                }
+                for (int e = 0; e < 4; e++) bv[e] = unpack_lo<T>(bias_all[f][e >> 1] >> (16 * (e & 1)));
             }
 #pragma unroll
             for (int g = 0; g < 4; g++) {
@@ -438,7 +451,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, 
 #pragma unroll
                         for (int e = 0; e < 4; e++) v[e] = rne(rne(v[e]) + rne(o[e]));
                     }
-                    if constexpr (WB) {   // (v is in the output type's grid after the outlier term: rounded once here otherwise)
+                    if constexpr (WB) {   // OutlierEpilogue bias (v is in the output type's grid after the outlier term: rounded once here otherwise)
 #pragma unroll
                         for (int e = 0; e < 4; e++) v[e] = rne((WO ? v[e] : rne(v[e])) + bb[e]);
                     }
@@ -492,6 +505,9 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, 
             if (ep.bias != nullptr) epilogue16(No{}, Yes{});
             else epilogue16(No{}, No{});
         }
+    } else if constexpr (!I8) {
+        if (bias != nullptr) epilogue16(No{}, Yes{});
+        else epilogue16(No{}, No{});
     } else {
         epilogue16(No{}, No{});
     }
