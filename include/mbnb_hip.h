@@ -273,8 +273,8 @@ int mbnb_embedding_8bit(const int64_t *indices, int64_t n_indices, const int8_t 
  *   out    = RNE(RNE(main + RNE(X[:, outlier_idx] . outlier_w^T)) + bias)               (:141-143, :110-111)
  * n_outliers may be 0 (pure INT8 path, :100-105).  `workspace` holds the int8 activations, their row scales and the
  * compact outlier activations [M, 16 * ceil(n_outliers / 16)]: mbnb_outlier_linear_workspace_bytes_n(M, K, n_outliers)
- * bytes let the 256 x 256 kernels fold ANY number of outlier columns (and the bias) into their epilogue (at most 32 columns
- * on >= 96 tiles: the four-wave kernel, one 16 x 16 x 32 MFMA per output fragment; otherwise the eight-wave kernel, one MFMA
+ * bytes let the 256 x 256 kernels fold ANY number of outlier columns (and the bias) into their epilogue (at most 64 columns
+ * on >= 96 tiles: the four-wave kernel, one 16 x 16 x 32 MFMA per output fragment and 32 columns; otherwise the eight-wave kernel, one MFMA
  * per tile and 16 columns); the two-argument query (and mbnb_outlier_linear, which assumes it) has room for 16 columns --
  * with more than that the outlier term runs as a separate pass over the output (same results).
  * ------------------------------------------------------------------------- */

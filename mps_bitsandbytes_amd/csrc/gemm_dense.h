@@ -67,7 +67,8 @@ template <int FM> struct GdPlan {
 // the reference's rounding chain -- per 16 x 16 output fragment ONE 16 x 16 x 32 MFMA of the 16-bit outlier weights [n, <= 32]
 // and the row's compact outlier activations [m, <= 32] (zero padded), operands straight from global / L2.  OUTL = 1: f16 outputs,
 // 2: bf16 outputs (the rounding chain is compiled for one type: every instruction of this epilogue runs 256 times per lane).
-template <typename T, bool SPLITK, int FM = 8, bool I8 = false, int OUTL = 0>
+// NCH: chunks of 32 outlier columns (1 or 2; f32 accumulation runs through the chunks, one rounding, as the reference's single GEMM).
+template <typename T, bool SPLITK, int FM = 8, bool I8 = false, int OUTL = 0, int NCH = 1>
 __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, const T *__restrict__ Wd, const T *__restrict__ bias,
                                                        void *__restrict__ out_v, int out_dtype, float *__restrict__ partial,
                                                        int64_t M, int64_t N, int64_t K, int64_t ldw, int64_t k_per_slice,
@@ -313,9 +314,9 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, 
     // OUTL operands, all requested here in one burst (inside the fragment loops each load would cost a full memory latency:
     // the accumulator reads below are ordered asm): per 16-column group f the outlier weights of row n = 16 f + er16 (8 per
     // lane at outlier index 8 efq) and the four bias values of the lane's columns; per 16-row group the compact activations
-    u32x4 wfr_all[OUTL ? 8 : 1];
+    u32x4 wfr_all[OUTL ? 8 * NCH : 1];      // [chunk][f]
     u32x2 bias_all[(OUTL || !I8) ? 8 : 1];   // 16-bit forms: the kernel's own bias (in T) travels the same way
-    u32x4 xfr_all[OUTL ? FM : 1];
+    u32x4 xfr_all[OUTL ? FM * NCH : 1];     // [chunk][g]
     if constexpr (!I8) {
         if (bias != nullptr) {
             const uint16_t *bp = reinterpret_cast<const uint16_t *>(bias);
@@ -335,19 +336,22 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, 
     if constexpr (OUTL) {
 #pragma unroll
         for (int f = 0; f < 8; f++) {
-            wfr_all[f] = u32x4{0u, 0u, 0u, 0u};
             bias_all[f] = u32x2{0u, 0u};
-            if (with_outl) {
-                const uint16_t *ow = static_cast<const uint16_t *>(ep.ow);
-                int64_t n = n_base + 16 * f + er16;
-                n = n < N ? n : N - 1;
-                const int64_t j0 = 8 * efq;
-                if (ow_vec && j0 + 8 <= ep.n_out) wfr_all[f] = *reinterpret_cast<const u32x4 *>(ow + n * ep.n_out + j0);
-                else {
-                    uint32_t t[8];
 #pragma unroll
-                    for (int e = 0; e < 8; e++) t[e] = (j0 + e < ep.n_out) ? (uint32_t)ow[n * ep.n_out + j0 + e] : 0u;
-                    wfr_all[f] = u32x4{t[0] | (t[1] << 16), t[2] | (t[3] << 16), t[4] | (t[5] << 16), t[6] | (t[7] << 16)};
+            for (int c = 0; c < NCH; c++) {
+                wfr_all[8 * c + f] = u32x4{0u, 0u, 0u, 0u};
+                if (with_outl) {
+                    const uint16_t *ow = static_cast<const uint16_t *>(ep.ow);
+                    int64_t n = n_base + 16 * f + er16;
+                    n = n < N ? n : N - 1;
+                    const int64_t j0 = 32 * c + 8 * efq;
+                    if (ow_vec && j0 + 8 <= ep.n_out) wfr_all[8 * c + f] = *reinterpret_cast<const u32x4 *>(ow + n * ep.n_out + j0);
+                    else if (j0 < ep.n_out) {
+                        uint32_t t[8];
+#pragma unroll
+                        for (int e = 0; e < 8; e++) t[e] = (j0 + e < ep.n_out) ? (uint32_t)ow[n * ep.n_out + j0 + e] : 0u;
+                        wfr_all[8 * c + f] = u32x4{t[0] | (t[1] << 16), t[2] | (t[3] << 16), t[4] | (t[5] << 16), t[6] | (t[7] << 16)};
+                    }
                 }
             }
             if (ep.bias != nullptr) {
@@ -364,12 +368,16 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, 
         }
 #pragma unroll
         for (int g = 0; g < FM; g++) {
-            xfr_all[g] = u32x4{0u, 0u, 0u, 0u};
-            if (with_outl) {
-                const uint16_t *xx = static_cast<const uint16_t *>(ep.x);
-                int64_t m = m0 + wm * 16 * FM + 16 * g + er16;
-                m = m < M ? m : M - 1;
-                if (8 * efq < ep.ldx) xfr_all[g] = *reinterpret_cast<const u32x4 *>(xx + m * ep.ldx + 8 * efq);
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
+                xfr_all[FM * c + g] = u32x4{0u, 0u, 0u, 0u};
+                if (with_outl) {
+                    const uint16_t *xx = static_cast<const uint16_t *>(ep.x);
+                    int64_t m = m0 + wm * 16 * FM + 16 * g + er16;
+                    m = m < M ? m : M - 1;
+                    const int64_t j0 = 32 * c + 8 * efq;
+                    if (j0 < ep.ldx) xfr_all[FM * c + g] = *reinterpret_cast<const u32x4 *>(xx + m * ep.ldx + j0);
+                }
             }
         }
     }
@@ -447,7 +455,9 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, 
                     if constexpr (WO) {
                         f32x4 o = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
                         using OFrag = typename Mfma16<OutlT>::frag;
-                        o = Mfma16<OutlT>::run(__builtin_bit_cast(OFrag, wfr_all[f]), __builtin_bit_cast(OFrag, xfr_all[4 * H + g]), o);
+#pragma unroll
+                        for (int c = 0; c < NCH; c++)
+                            o = Mfma16<OutlT>::run(__builtin_bit_cast(OFrag, wfr_all[8 * c + f]), __builtin_bit_cast(OFrag, xfr_all[FM * c + 4 * H + g]), o);
 #pragma unroll
                         for (int e = 0; e < 4; e++) v[e] = rne(rne(v[e]) + rne(o[e]));
                     }

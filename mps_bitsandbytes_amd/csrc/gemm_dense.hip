@@ -166,13 +166,15 @@ bool gemm_i8_dense_shape(int64_t M, int64_t N, int64_t K) {
 }
 // ep != nullptr (OutlierAwareLinear): outlier term and bias in the epilogue; the caller checks gemm_i8_dense_outlier_ok first.
 bool gemm_i8_dense_outlier_ok(const OutlierEpilogue &ep, int out_dtype) {
-    return out_dtype != MBNB_F32 && (ep.x == nullptr || ep.n_out == 0 || (ep.ldx <= 32 && ep.ldx % 16 == 0 && (reinterpret_cast<uintptr_t>(ep.x) & 15) == 0));
+    return out_dtype != MBNB_F32 && (ep.x == nullptr || ep.n_out == 0 || (ep.ldx <= 64 && ep.ldx % 16 == 0 && (reinterpret_cast<uintptr_t>(ep.x) & 15) == 0));
 }
 int launch_gemm_i8_dense(const int8_t *A, const int8_t *Bt, const float *sA, const float *sB, int64_t M, int64_t N, int64_t K,
                          int out_dtype, void *out, hipStream_t st, const OutlierEpilogue *ep) {
     const int64_t tiles = ((M + 255) / 256) * ((N + 255) / 256);
     if (ep != nullptr) {
-        auto kern = out_dtype == MBNB_F16 ? k_gemm_dense<bf16_t, false, 8, true, 1> : k_gemm_dense<bf16_t, false, 8, true, 2>;
+        const bool two = ep->x != nullptr && ep->n_out > 0 && ep->ldx > 32;   // chunks of 32 outlier columns
+        auto kern = out_dtype == MBNB_F16 ? (two ? k_gemm_dense<bf16_t, false, 8, true, 1, 2> : k_gemm_dense<bf16_t, false, 8, true, 1, 1>)
+                                          : (two ? k_gemm_dense<bf16_t, false, 8, true, 2, 2> : k_gemm_dense<bf16_t, false, 8, true, 2, 1>);
         if (int rc = ensure_dyn_lds(reinterpret_cast<const void *>(kern), GD_LDS, "matmul_int8(dense+outliers)")) return rc;
         hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), GD_LDS, st, reinterpret_cast<const bf16_t *>(A),
                            reinterpret_cast<const bf16_t *>(Bt), static_cast<const bf16_t *>(nullptr), out, out_dtype,

@@ -486,8 +486,8 @@ int matmul_int8_nt_dispatch(const int8_t *A, const int8_t *Bt, const float *sA, 
         set_kernel_name("i8_generic");
         return check_launch("matmul_int8(generic nt)");
     }
-    // OutlierAwareLinear with at most 32 outlier columns: the four-wave pipeline of gemm_dense.h, outlier term and bias in
-    // its epilogue (one 16 x 16 x 32 MFMA per output fragment)
+    // OutlierAwareLinear with at most 64 outlier columns: the four-wave pipeline of gemm_dense.h, outlier term and bias in
+    // its epilogue (one 16 x 16 x 32 MFMA per output fragment and 32 columns)
     if (ep != nullptr && gemm_i8_dense_shape(M, N, K) && gemm_i8_dense_outlier_ok(*ep, out_dtype)) {
         const int rc = launch_gemm_i8_dense(A, Bt, sA, sB, M, N, K, out_dtype, out, st, ep);
         if (ep_done) *ep_done = true;

@@ -133,16 +133,18 @@ def test_outlier_linear_golden(g6):
                                                   (2560, 512, 2560, torch.float16, 21, True), (2600, 256, 2500, torch.bfloat16, 64, True),
                                                   (4096, 4096, 4096, torch.bfloat16, 16, True), (2560, 512, 2560, torch.bfloat16, 0, True),
                                                   (2500, 384, 2608, torch.float16, 32, False), (2560, 640, 2568, torch.bfloat16, 7, True),
-                                                  (2560, 256, 2508, torch.bfloat16, 5, True), (2400, 512, 2507, torch.float16, 16, True)])
+                                                  (2560, 256, 2508, torch.bfloat16, 5, True), (2400, 512, 2507, torch.float16, 16, True),
+                                                  (2560, 512, 2560, torch.float16, 70, True), (2304, 1024, 2816, torch.float16, 33, False)])
 def test_outlier_linear_vs_oracle(M, K, N, dt, n_out, bias):
     """MFMA-sized shapes (256^2 and 128^2 int8 kernels), ragged K (generic kernel), with / without outliers and bias; on the
     eight-wave 256^2 kernel the outlier columns ride in the epilogue in chunks of 16 (40 and 64 columns: three / four chunks,
-    ragged last chunk); with at most 32 of them on >= 96 tiles the four-wave kernel of gemm_dense.h carries them (21: weight
+    ragged last chunk; here 70); with at most 64 of them on >= 96 tiles the four-wave kernel of gemm_dense.h carries them in one
+    or two chunks of 32 (33, 40, 64: two; 21: weight
     rows not 16-byte aligned; 0 + bias; ragged M / N, N not a multiple of 8 / odd: scalar stores and the bias tail; the 4096^3 bench
     shape)."""
     want = None
     if K % 128 == 0 and K >= 256 and ((M + 255) // 256) * ((N + 255) // 256) >= 96 and (n_out > 0 or bias):
-        want = "i8_dense+outliers" if n_out <= 32 else "i8_mfma256"
+        want = "i8_dense+outliers" if n_out <= 64 else "i8_mfma256"
     W = synthetic.normal((N, K), torch.float32, seed=821, std=0.05)
     oidx = torch.from_numpy(np.sort((synthetic.uniform_u64(4 * n_out + 1, seed=822) % np.uint64(K)).astype(np.int64))).unique()[:n_out]
     W[:, oidx] *= 30.0
