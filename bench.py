@@ -76,6 +76,15 @@ def event_time_ms(fn, steps):
     return e0.elapsed_time(e1) / steps
 
 
+def _outlier_traffic():
+    """HBM bytes per launch of the OutlierAwareLinear GEMM from the committed PMC passes (tools/profile_round.sh), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            return json.load(f).get("k_gemm_i8_outlier_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
 def bench_nn(args, wl, dev, bnb, synthetic):
     """SURVEY 8f rank-3 rows on one GPU: 4-bit / 8-bit embedding lookups (HBM-bound gathers over a 32000 x 4096 table,
     8192 looked-up rows per step) and OutlierAwareLinear.forward (4096^3, 16 outlier columns, int8 MFMA)."""
@@ -196,8 +205,8 @@ def bench_nn(args, wl, dev, bnb, synthetic):
                 "value": round(ops / (elapsed / args.steps) / 1e12, 1), "unit": "TOP/s", "ms_per_step": round(elapsed / args.steps * 1e3, 5),
                 "dtype": "int8", "config": {"workload": "OutlierAwareLinear.forward, fp16 activations, 16 outlier columns, bias", "M": M, "N": N, "K": K},
                 "roofline": {"bound": "mfma", "achieved": round(tops, 1), "peak": PEAK_TFLOPS["int8"], "unit": "TOP/s",
-                             "frac": round(tops / PEAK_TFLOPS["int8"], 4), "traffic": None, "kernel_us": round(kern_ms * 1e3, 2),
-                             "note": "whole forward (3 kernels) / int8 dense peak"}})
+                             "frac": round(tops / PEAK_TFLOPS["int8"], 4), "traffic": _outlier_traffic(), "kernel_us": round(kern_ms * 1e3, 2),
+                             "note": "whole forward (2 kernels: masked row-wise quantiser + int8 GEMM with the outlier term and bias in its epilogue) / int8 dense peak; traffic: PMC bytes of the GEMM launch (profiles/traffic.json)"}})
     if not args.no_cpu_baseline:
         rows = 256
         xs = x[:rows].cpu()

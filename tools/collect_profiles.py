@@ -88,7 +88,10 @@ if "FETCH_SIZE" in res:
     out["counters"] = res
     # HBM traffic of the GEMV (M = 1, 64 rotating layers) and of the int8 GEMM, same counters and correction
     for wl, sub, key, alg in (("nf4_m1", "k_gemv4", "k_gemv4_bytes_per_launch", 9453568),
-                              ("int8_4096", "k_gemm_dense", "k_gemm_i8_bytes_per_launch", 2 * 4096 * 4096 + 4096 * 4096 * 2 + 2 * 4096 * 4)):   # the int8 form of k_gemm_dense (the transpose pass is a separate kernel)
+                              ("int8_4096", "k_gemm_dense", "k_gemm_i8_bytes_per_launch", 2 * 4096 * 4096 + 4096 * 4096 * 2 + 2 * 4096 * 4),   # the int8 form of k_gemm_dense (the transpose pass is a separate kernel)
+                              # OutlierAwareLinear's GEMM: int8 A and W, 16-bit out, scales, 16 outlier columns (compact activations, weights), bias
+                              ("outlier", "k_gemm_dense", "k_gemm_i8_outlier_bytes_per_launch",
+                               2 * 4096 * 4096 + 4096 * 4096 * 2 + 2 * 4096 * 4 + 2 * 4096 * 16 * 2 + 4096 * 2)):
         f = kernel_counter_mean(f"{tag}_{wl}_fetch", sub, "FETCH_SIZE")
         w = kernel_counter_mean(f"{tag}_{wl}_write", sub, "WRITE_SIZE")
         if f and w:

@@ -26,8 +26,8 @@ echo "traffic passes done"
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --output-format csv -d $o/${tag}_sq -- python3 bench.py $small > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $o/${tag}_lds -- python3 bench.py $small > /dev/null 2>&1
 echo "sq passes done"
-# HBM traffic of the M = 1 GEMV (64 rotating layers) and of the int8 GEMM: FETCH_SIZE and WRITE_SIZE in separate passes
-for wl in nf4_m1 int8_4096; do
+# HBM traffic of the M = 1 GEMV (64 rotating layers), of the int8 GEMM and of OutlierAwareLinear's GEMM: FETCH_SIZE and WRITE_SIZE in separate passes
+for wl in nf4_m1 int8_4096 outlier; do
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $o/${tag}_${wl}_fetch -- python3 bench.py --workload $wl $small > /dev/null 2>&1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $o/${tag}_${wl}_write -- python3 bench.py --workload $wl $small > /dev/null 2>&1
 done
