@@ -64,6 +64,40 @@ def parse():
     return ap.parse_args()
 
 
+def probe_lib():
+    """tools/libmbnb_probe.so (bare MFMA loop for the `roofline.empirical` context figures; NOT part of the product library),
+    or None when it has not been built."""
+    import ctypes
+    path = os.path.join(ROOT, "tools", "libmbnb_probe.so")
+    if not os.path.exists(path):
+        return None
+    lib = ctypes.CDLL(path)
+    lib.mbnb_probe_mfma.restype = ctypes.c_int64
+    lib.mbnb_probe_mfma.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    return lib
+
+
+def bare_mfma_rate(kind):
+    """Sustained rate (T op/s) of a bare MFMA loop on every SIMD of this box (kind 0: bf16 32x32x16, 1: i8 32x32x32), or None."""
+    lib = probe_lib()
+    if lib is None:
+        return None
+    sink = torch.zeros(1, dtype=torch.float32, device="cuda")
+    stp = torch.cuda.current_stream().cuda_stream
+    if lib.mbnb_probe_mfma(kind, 2000, sink.data_ptr(), stp) <= 0:
+        return None
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    n_mfma = 0
+    for _ in range(10):
+        n_mfma += int(lib.mbnb_probe_mfma(kind, 20000, sink.data_ptr(), stp))
+    e1.record()
+    e1.synchronize()
+    per = 32768.0 if kind == 0 else 65536.0     # 2*32*32*16 / 2*32*32*32 operations per MFMA
+    return n_mfma * per / (e0.elapsed_time(e1) * 1e-3) / 1e12 if n_mfma > 0 else None
+
+
 def event_time_ms(fn, steps):
     """Average duration of fn() over `steps` back-to-back launches, HIP events on the current stream."""
     st = torch.cuda.current_stream()
@@ -751,21 +785,9 @@ def main():
                 dst.copy_(src)
                 copy_ms = min(event_time_ms(lambda: dst.copy_(src), 10) for _ in range(3))
                 del src, dst
-                # what the matrix pipe sustains on THIS box: a bare bf16 MFMA loop on every SIMD (mbnb_probe_mfma); the
+                # what the matrix pipe sustains on THIS box: a bare bf16 MFMA loop on every SIMD (tools/libmbnb_probe.so); the
                 # spec peak assumes 2.4 GHz, the chip holds much less under MFMA load
-                sink = torch.zeros(1, dtype=torch.float32, device=dev)
-                stp = torch.cuda.current_stream().cuda_stream
-                lib = _native.lib()
-                lib.mbnb_probe_mfma(0, 2000, sink.data_ptr(), stp)
-                torch.cuda.synchronize()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                n_mfma = 0
-                for _ in range(10):
-                    n_mfma += int(lib.mbnb_probe_mfma(0, 20000, sink.data_ptr(), stp))
-                e1.record()
-                e1.synchronize()
-                mfma_tflops = n_mfma * 32768.0 / (e0.elapsed_time(e1) * 1e-3) / 1e12 if n_mfma > 0 else None   # 2*32*32*16 flop per MFMA
+                mfma_tflops = bare_mfma_rate(0)
                 out["roofline"]["empirical"] = {
                     "vendor_blas_bf16_same_shape_tflops": round(2.0 * M * N * K / (blas_ms * 1e-3) / 1e12, 1),
                     "vendor_blas_us": round(blas_ms * 1e3, 1),
@@ -777,21 +799,10 @@ def main():
     if rank == 0 and wl == "int8_4096" and not args.no_empirical:
         # what the int8 matrix pipe sustains on THIS box (bare v_mfma_i32_32x32x32_i8 loop, one wave per SIMD)
         try:
-            sink = torch.zeros(1, dtype=torch.float32, device=dev)
-            stp = torch.cuda.current_stream().cuda_stream
-            lib = _native.lib()
-            lib.mbnb_probe_mfma(1, 2000, sink.data_ptr(), stp)
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            n_mfma = 0
-            for _ in range(10):
-                n_mfma += int(lib.mbnb_probe_mfma(1, 20000, sink.data_ptr(), stp))
-            e1.record()
-            e1.synchronize()
-            if n_mfma > 0:
+            i8_tops = bare_mfma_rate(1)
+            if i8_tops is not None:
                 out["roofline"]["empirical"] = {
-                    "bare_mfma_loop_i8_tops": round(n_mfma * 65536.0 / (e0.elapsed_time(e1) * 1e-3) / 1e12, 1),   # 2*32*32*32 per MFMA
+                    "bare_mfma_loop_i8_tops": round(i8_tops, 1),
                     "bare_mfma_note": "v_mfma_i32_32x32x32_i8 back to back on every SIMD, nothing else: the sustained int8 matrix rate at the clock the chip holds under that load"}
         except Exception as e:  # context only
             out["roofline"]["empirical"] = {"error": str(e)[:200]}

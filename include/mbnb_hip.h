@@ -55,13 +55,6 @@ const char *mbnb_last_error(void);
  * dispatched to ("gemv", "mfma128", "generic", ...) — for tests and the bench driver */
 const char *mbnb_last_kernel(void);
 
-/* Measurement aid (bench.py `roofline.empirical`; not part of the reference boundary): launches a bare MFMA loop -- one wave
- * per SIMD on 256 workgroups, four independent accumulators, `iters` iterations of four v_mfma_f32_32x32x16_bf16 (kind 0) or
- * v_mfma_i32_32x32x32_i8 (kind 1) -- on `stream` and returns the number of MFMA wave-instructions issued (> 0), or a status
- * (<= 0 / hipError_t) on failure.  The caller times it: sustained rate = return value * 32768 (bf16) or 65536 (i8) ops / time.
- * `sink`: 4 device bytes, never written in practice. */
-int64_t mbnb_probe_mfma(int kind, int iters, float *sink, void *stream);
-
 /* ---------------------------------------------------------------------------
  * Absmax descriptor used by the 4-bit consumers.  Either plain f32 absmax
  * (absmax_i8 == NULL), or the reference's "double quantised" form
@@ -220,7 +213,13 @@ int mbnb_matmul_4bit_ex(const void *A, int64_t M, int64_t K, const uint8_t *pack
  * aligned; f32 accumulation, one rounding to `dtype`, then the cast to out_dtype.  `slices`: bits 0-7 the number of K
  * slices (> 1 splits K over slices * M * N * 4 bytes of workspace, partials added in slice order; 1 needs no workspace);
  * bits 8-15 the row extent of a tile in units of 128 rows: 0 = the library's choice, 1 = 256 (n) x 128 (m) tiles, 2 =
- * 256 x 256.  The tile shape does not change the result's bits, the slice count does. */
+ * 256 x 256.  The tile shape does not change the result's bits, the slice count does.  Slice count 0 = the library's own plan
+ * for this shape (what mbnb_matmul_4bit_ws / mbnb_linear_int8_ws run after their dequantise pass, so a caller that keeps the
+ * dequantised weight -- Linear8bit's cache, nn/linear8bit.py:70-85 -- gets the same bits); its partials need
+ * mbnb_gemm_dense_workspace_bytes(M, N, K) bytes (0 when the plan does not split), a shorter workspace means one slice.
+ * mbnb_gemm_dense_applies: 1 when the decode-once path serves this shape (from 256 rows and 1.5 M outputs up), else 0. */
+int mbnb_gemm_dense_applies(int64_t M, int64_t N, int64_t K, int64_t ldw);
+int64_t mbnb_gemm_dense_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int mbnb_gemm_dense(const void *A, const void *W, int dtype, const void *bias, int out_dtype, void *out,
                     int64_t M, int64_t N, int64_t K, int64_t ldw, void *workspace, int64_t workspace_bytes,
                     int slices, void *stream);
@@ -243,6 +242,11 @@ int64_t mbnb_linear_int8_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int mbnb_linear_int8_ws(const void *X, int dtype, int64_t M, int64_t K, const int8_t *W,
                         const float *W_scales, int64_t N, const void *bias, void *out, void *workspace,
                         int64_t workspace_bytes, void *stream);
+/* mbnb_linear_int8_ws with a flags word: MBNB_MATMUL_FUSED_ONLY keeps the fused W8A16 kernels at every M, whatever the
+ * workspace could hold (it then serves split-K only); 0 = mbnb_linear_int8_ws. */
+int mbnb_linear_int8_ex(const void *X, int dtype, int64_t M, int64_t K, const int8_t *W,
+                        const float *W_scales, int64_t N, const void *bias, void *out, void *workspace,
+                        int64_t workspace_bytes, int flags, void *stream);
 
 /* ---------------------------------------------------------------------------
  * embedding_4bit — replaces `_C.embedding_4bit_nf4` / `_C.embedding_4bit_fp4` (host mm:2309-2388, kernels
@@ -303,6 +307,10 @@ int mbnb_dequantize_fp8_e4m3(const uint8_t *q, const float *scales, int64_t rows
                              void *out, void *stream);
 int mbnb_linear_fp8(const void *X, int dtype, int64_t M, int64_t K, const uint8_t *W, const float *W_scales,
                     int64_t N, const void *bias, void *out, void *workspace, int64_t workspace_bytes, void *stream);
+/* with the flags word of mbnb_linear_int8_ex (MBNB_MATMUL_FUSED_ONLY) */
+int mbnb_linear_fp8_ex(const void *X, int dtype, int64_t M, int64_t K, const uint8_t *W, const float *W_scales,
+                       int64_t N, const void *bias, void *out, void *workspace, int64_t workspace_bytes, int flags,
+                       void *stream);
 
 #ifdef __cplusplus
 }

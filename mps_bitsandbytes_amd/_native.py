@@ -37,7 +37,6 @@ _SIGNATURES = {
     "mbnb_abi_version": (c_int, []),
     "mbnb_last_error": (c_char_p, []),
     "mbnb_last_kernel": (c_char_p, []),
-    "mbnb_probe_mfma": (c_int64, [c_int, c_int, c_void_p, c_void_p]),
     "mbnb_quantize_4bit": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_int, c_int, c_void_p,
                                    c_void_p, c_void_p, c_void_p]),
     "mbnb_quantize_4bit_dq": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p,
@@ -58,6 +57,8 @@ _SIGNATURES = {
     "mbnb_matmul_4bit_workspace_bytes_dt": (c_int64, [c_int64, c_int64, c_int64, c_int64, c_int]),
     "mbnb_matmul_4bit_splitk_workspace_bytes": (c_int64, [c_int64, c_int64, c_int64]),
     "mbnb_linear_int8_workspace_bytes": (c_int64, [c_int64, c_int64, c_int64]),
+    "mbnb_gemm_dense_applies": (c_int, [c_int64, c_int64, c_int64, c_int64]),
+    "mbnb_gemm_dense_workspace_bytes": (c_int64, [c_int64, c_int64, c_int64]),
     "mbnb_gemm_dense": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p,
                         c_int64, c_int, c_void_p]),
     "mbnb_matmul_4bit_ws": (c_int, [c_void_p, c_int64, c_int64, c_void_p, POINTER(AbsmaxDesc), c_int64, c_int64,
@@ -71,6 +72,10 @@ _SIGNATURES = {
                                  c_void_p, c_void_p]),
     "mbnb_linear_int8_ws": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
                                     c_void_p, c_void_p, c_int64, c_void_p]),
+    "mbnb_linear_int8_ex": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
+                                    c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "mbnb_linear_fp8_ex": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
+                                   c_void_p, c_int64, c_int, c_void_p]),
     "mbnb_quantize_fp8_e4m3": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "mbnb_dequantize_fp8_e4m3": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p]),
     "mbnb_linear_fp8": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,

@@ -68,18 +68,19 @@ int matmul_4bit_dispatch(const void *, int64_t, int64_t, const uint8_t *, const 
                          hipStream_t);
 int quantize_fp8_dispatch(const void *, int, int64_t, int64_t, uint8_t *, float *, hipStream_t);
 int dequantize_fp8_dispatch(const uint8_t *, const float *, int64_t, int64_t, int, void *, hipStream_t);
-int linear_fp8_dispatch(const void *, int, int64_t, int64_t, const uint8_t *, const float *, int64_t, const void *, void *, void *, int64_t, hipStream_t);
+int linear_fp8_dispatch(const void *, int, int64_t, int64_t, const uint8_t *, const float *, int64_t, const void *, void *, void *, int64_t, bool, hipStream_t);
 int64_t matmul4_splitk_slices(int64_t, int64_t, int64_t);
-int probe_mfma_dispatch(int, int, float *, hipStream_t);
 int64_t gemm_mid_workspace_bytes(int64_t, int64_t, int64_t);
 int64_t gemm_small_workspace_bytes(int64_t, int64_t, int64_t, int64_t);
 int64_t gemm_f32_workspace_bytes(int64_t, int64_t, int64_t, int64_t);
 int64_t gemm_dense_workspace_bytes(int64_t, int64_t, int64_t, int64_t);
+bool gemm_dense_shape(int64_t, int64_t, int64_t, int64_t);
+int64_t gemm_dense_slices(int64_t, int64_t, int64_t);
 int gemm_dense_direct(const void *, const void *, int, const void *, int, void *, int64_t, int64_t, int64_t, int64_t, float *, int64_t, int,
                       hipStream_t);
 int matmul_int8_dispatch(const int8_t *, const int8_t *, const float *, const float *, int64_t, int64_t, int64_t, int, void *, void *, hipStream_t);
 int64_t matmul_int8_workspace_bytes(int64_t, int64_t, int64_t);
-int linear_int8_dispatch(const void *, int, int64_t, int64_t, const int8_t *, const float *, int64_t, const void *, void *, void *, int64_t, hipStream_t);
+int linear_int8_dispatch(const void *, int, int64_t, int64_t, const int8_t *, const float *, int64_t, const void *, void *, void *, int64_t, bool, hipStream_t);
 int embedding_4bit_dispatch(const int64_t *, int64_t, const uint8_t *, const float *, int64_t, int64_t, int, int, int, int64_t, int, void *, hipStream_t);
 int embedding_8bit_dispatch(const int64_t *, int64_t, const int8_t *, const float *, int64_t, int64_t, int, int64_t, int, void *, hipStream_t);
 int outlier_linear_dispatch(const void *, int, int64_t, int64_t, const int8_t *, const float *, int64_t, const int64_t *, int64_t, const void *, const void *, void *, void *, int64_t, hipStream_t);
@@ -118,12 +119,6 @@ extern "C" {
 
 int mbnb_abi_version(void) { return MBNB_ABI_VERSION; }
 
-int64_t mbnb_probe_mfma(int kind, int iters, float *sink, void *stream) {
-    if ((kind != 0 && kind != 1) || iters <= 0 || !sink) return fail(MBNB_ERR_ARG, "probe_mfma: bad argument");
-    if (int rc = probe_mfma_dispatch(kind, iters, sink, static_cast<hipStream_t>(stream))) return rc;
-    // matrix operations issued by the launch: 256 workgroups x 4 waves x 4 MFMAs per iteration
-    return (int64_t)256 * 4 * 4 * iters;
-}
 const char *mbnb_last_error(void) { return g_err; }
 const char *mbnb_last_kernel(void) { return g_kernel; }
 
@@ -317,11 +312,24 @@ int mbnb_gemm_dense(const void *A, const void *W, int dtype, const void *bias, i
     if (!A || !W || !out) return fail(MBNB_ERR_ARG, "gemm_dense: NULL pointer");
     if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(W) & 15))
         return fail(MBNB_ERR_ARG, "gemm_dense: operands must be 16-byte aligned");
+    if (slices == 0) {   // the library's plan (what mbnb_matmul_4bit_ws / mbnb_linear_int8_ws run), as far as the workspace allows
+        slices = (int)gemm_dense_slices(M, N, K);
+        if (slices > 1 && (!workspace || workspace_bytes < (int64_t)slices * M * N * 4)) slices = 1;
+    }
     if (slices < 1 || slices > 16 || (int64_t)slices * 64 > K) return fail(MBNB_ERR_ARG, "gemm_dense: bad slice count");
     if (slices > 1 && (!workspace || workspace_bytes < (int64_t)slices * M * N * 4 || (reinterpret_cast<uintptr_t>(workspace) & 15)))
         return fail(MBNB_ERR_ARG, "gemm_dense: split-K needs slices * M * N * 4 bytes of 16-byte aligned workspace");
     return gemm_dense_direct(A, W, dtype, bias, out_dtype, out, M, N, K, ldw, static_cast<float *>(workspace), slices, tile_m,
                              static_cast<hipStream_t>(stream));
+}
+
+int mbnb_gemm_dense_applies(int64_t M, int64_t N, int64_t K, int64_t ldw) {
+    return (M > 0 && N > 0 && K > 0 && ldw >= K && gemm_dense_shape(M, N, K, ldw)) ? 1 : 0;
+}
+int64_t mbnb_gemm_dense_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+    if (M <= 0 || N <= 0 || K < 128 || K % 64) return 0;
+    const int64_t s = gemm_dense_slices(M, N, K);
+    return s > 1 ? s * M * N * 4 : 0;
 }
 
 int64_t mbnb_matmul_int8_workspace_bytes(int64_t M, int64_t N, int64_t K) {
@@ -339,14 +347,20 @@ int mbnb_matmul_int8(const int8_t *A, const int8_t *B, const float *A_scales, co
                                 static_cast<hipStream_t>(stream));
 }
 
-int mbnb_linear_int8_ws(const void *X, int dtype, int64_t M, int64_t K, const int8_t *W, const float *W_scales, int64_t N,
-                        const void *bias, void *out, void *workspace, int64_t workspace_bytes, void *stream) {
+int mbnb_linear_int8_ex(const void *X, int dtype, int64_t M, int64_t K, const int8_t *W, const float *W_scales, int64_t N,
+                        const void *bias, void *out, void *workspace, int64_t workspace_bytes, int flags, void *stream) {
+    if (flags & ~MBNB_MATMUL_FUSED_ONLY) return fail(MBNB_ERR_ARG, "linear_int8: unknown flags 0x%x", flags);
     if (!dtype_ok(dtype)) return fail(MBNB_ERR_ARG, "linear_int8: bad dtype");
     if (M < 0 || N < 0 || K < 0) return fail(MBNB_ERR_ARG, "linear_int8: negative size");
     if (M == 0 || N == 0) return MBNB_OK;
     if (!X || !W || !W_scales || !out) return fail(MBNB_ERR_ARG, "linear_int8: NULL pointer");
     return linear_int8_dispatch(X, dtype, M, K, W, W_scales, N, bias, out, workspace, workspace ? workspace_bytes : 0,
-                                static_cast<hipStream_t>(stream));
+                                (flags & MBNB_MATMUL_FUSED_ONLY) != 0, static_cast<hipStream_t>(stream));
+}
+
+int mbnb_linear_int8_ws(const void *X, int dtype, int64_t M, int64_t K, const int8_t *W, const float *W_scales, int64_t N,
+                        const void *bias, void *out, void *workspace, int64_t workspace_bytes, void *stream) {
+    return mbnb_linear_int8_ex(X, dtype, M, K, W, W_scales, N, bias, out, workspace, workspace_bytes, 0, stream);
 }
 
 int mbnb_linear_int8(const void *X, int dtype, int64_t M, int64_t K, const int8_t *W, const float *W_scales, int64_t N,
@@ -430,14 +444,20 @@ int mbnb_dequantize_fp8_e4m3(const uint8_t *q, const float *scales, int64_t rows
     return dequantize_fp8_dispatch(q, scales, rows, cols, out_dtype, out, static_cast<hipStream_t>(stream));
 }
 
-int mbnb_linear_fp8(const void *X, int dtype, int64_t M, int64_t K, const uint8_t *W, const float *W_scales, int64_t N,
-                    const void *bias, void *out, void *workspace, int64_t workspace_bytes, void *stream) {
+int mbnb_linear_fp8_ex(const void *X, int dtype, int64_t M, int64_t K, const uint8_t *W, const float *W_scales, int64_t N,
+                       const void *bias, void *out, void *workspace, int64_t workspace_bytes, int flags, void *stream) {
+    if (flags & ~MBNB_MATMUL_FUSED_ONLY) return fail(MBNB_ERR_ARG, "linear_fp8: unknown flags 0x%x", flags);
     if (!dtype_ok(dtype)) return fail(MBNB_ERR_ARG, "linear_fp8: bad dtype");
     if (M < 0 || N < 0 || K < 0) return fail(MBNB_ERR_ARG, "linear_fp8: negative size");
     if (M == 0 || N == 0) return MBNB_OK;
     if (!X || !W || !W_scales || !out) return fail(MBNB_ERR_ARG, "linear_fp8: NULL pointer");
     return linear_fp8_dispatch(X, dtype, M, K, W, W_scales, N, bias, out, workspace, workspace ? workspace_bytes : 0,
-                               static_cast<hipStream_t>(stream));
+                               (flags & MBNB_MATMUL_FUSED_ONLY) != 0, static_cast<hipStream_t>(stream));
+}
+
+int mbnb_linear_fp8(const void *X, int dtype, int64_t M, int64_t K, const uint8_t *W, const float *W_scales, int64_t N,
+                    const void *bias, void *out, void *workspace, int64_t workspace_bytes, void *stream) {
+    return mbnb_linear_fp8_ex(X, dtype, M, K, W, W_scales, N, bias, out, workspace, workspace_bytes, 0, stream);
 }
 
 }  // extern "C"

@@ -231,6 +231,9 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // ---------------------------------------------------------------- host side
+// Internal status of the per-path launchers ("this path does not serve the call, try the next one").  Never crosses the C ABI,
+// and cannot collide with a hipError_t (> 0; hipErrorInvalidValue == 1) or an MBNB_ERR_* code (-1 .. -3).
+constexpr int MBNB_NOT_APPLICABLE = -1000;
 void set_error(const char *fmt, ...);
 void set_kernel_name(const char *name);
 int check_launch(const char *what);

@@ -100,15 +100,15 @@ static int launch_gemm_dense(const T *x, const T *wd, const T *bias, void *out, 
     return launch_gemm_dense_fm<T, 8>(x, wd, bias, out, out_dtype, M, N, K, ldw, partial, slices, st);
 }
 
-// Returns 1 when the path does not apply (caller falls through to the fused kernels), otherwise the launch status.
+// Returns MBNB_NOT_APPLICABLE when the path does not apply (caller falls through to the fused kernels), otherwise the launch status.
 int matmul_4bit_dense_path(const void *A, int64_t M, int64_t K, const uint8_t *packed, const AbsmaxView &am, int64_t N,
                            int64_t K_weight, int blocksize, int qt, int w_dtype, const void *bias, int out_dtype, void *out,
                            void *ws, int64_t ws_bytes, hipStream_t st) {
-    if (w_dtype != MBNB_F16 && w_dtype != MBNB_BF16) return 1;
-    if (!gemm_dense_shape(M, N, K, K_weight) || ws == nullptr) return 1;
-    if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(ws) & 255) || (reinterpret_cast<uintptr_t>(packed) & 3)) return 1;
+    if (w_dtype != MBNB_F16 && w_dtype != MBNB_BF16) return MBNB_NOT_APPLICABLE;
+    if (!gemm_dense_shape(M, N, K, K_weight) || ws == nullptr) return MBNB_NOT_APPLICABLE;
+    if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(ws) & 255) || (reinterpret_cast<uintptr_t>(packed) & 3)) return MBNB_NOT_APPLICABLE;
     const int64_t wd_bytes = gemm_dense_wd_bytes(N, K_weight);
-    if (ws_bytes < wd_bytes) return 1;
+    if (ws_bytes < wd_bytes) return MBNB_NOT_APPLICABLE;
     DensePlan plan = gemm_dense_plan(M, N, K);
     if (plan.slices > 1 && ws_bytes < wd_bytes + plan.slices * M * N * 4) plan.slices = 1;   // a short workspace costs the split, not the path
     const int64_t slices = plan.slices;
@@ -131,14 +131,14 @@ int dequantize_fp8_dispatch(const uint8_t *, const float *, int64_t, int64_t, in
 
 // Linear8bit.forward / LinearFP8.forward at large M (nn/linear8bit.py:70-102, functional.py:796-807): the reference's own two
 // steps -- dequantize_rowwise / dequantize_fp8_e4m3 into the compute dtype, then F.linear -- on the workspace.  Same policy
-// and workspace layout as the 4-bit path.  Returns 1 when it does not apply.
+// and workspace layout as the 4-bit path.  Returns MBNB_NOT_APPLICABLE when it does not apply.
 int linear8_dense_path(const void *X, int dtype, int64_t M, int64_t K, const void *W, const float *scales, int64_t N, bool fp8,
                        const void *bias, void *out, void *ws, int64_t ws_bytes, hipStream_t st) {
-    if (dtype != MBNB_F16 && dtype != MBNB_BF16) return 1;
-    if (!gemm_dense_shape(M, N, K, K) || ws == nullptr) return 1;
-    if ((reinterpret_cast<uintptr_t>(X) & 15) || (reinterpret_cast<uintptr_t>(ws) & 255)) return 1;
+    if (dtype != MBNB_F16 && dtype != MBNB_BF16) return MBNB_NOT_APPLICABLE;
+    if (!gemm_dense_shape(M, N, K, K) || ws == nullptr) return MBNB_NOT_APPLICABLE;
+    if ((reinterpret_cast<uintptr_t>(X) & 15) || (reinterpret_cast<uintptr_t>(ws) & 255)) return MBNB_NOT_APPLICABLE;
     const int64_t wd_bytes = gemm_dense_wd_bytes(N, K);
-    if (ws_bytes < wd_bytes) return 1;
+    if (ws_bytes < wd_bytes) return MBNB_NOT_APPLICABLE;
     DensePlan plan = gemm_dense_plan(M, N, K);
     if (plan.slices > 1 && ws_bytes < wd_bytes + plan.slices * M * N * 4) plan.slices = 1;
     const int64_t slices = plan.slices;

@@ -188,14 +188,14 @@ static int launch_gemm_f32(const float *x, const float *wd, const float *b, void
     return check_launch("matmul_4bit(dense_f32 split-K reduce)");
 }
 
-// Returns 1 when the path does not apply (the caller continues to the generic kernel), otherwise the launch status.
+// Returns MBNB_NOT_APPLICABLE when the path does not apply (the caller continues to the generic kernel), otherwise the launch status.
 int matmul_4bit_f32_path(const void *A, int64_t M, int64_t K, const uint8_t *packed, const AbsmaxView &am, int64_t N,
                          int64_t K_weight, int blocksize, int qt, const void *bias, int out_dtype, void *out, void *ws,
                          int64_t ws_bytes, hipStream_t st) {
-    if (ws == nullptr || !gemm_f32_shape(M, N, K, K_weight)) return 1;
+    if (ws == nullptr || !gemm_f32_shape(M, N, K, K_weight)) return MBNB_NOT_APPLICABLE;
     const int64_t wd_bytes = gemm_f32_wd_bytes(N, K_weight);
-    if (ws_bytes < wd_bytes) return 1;
-    if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(ws) & 15)) return 1;
+    if (ws_bytes < wd_bytes) return MBNB_NOT_APPLICABLE;
+    if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(ws) & 15)) return MBNB_NOT_APPLICABLE;
     F32Plan p = gemm_f32_plan(M, N, K);
     if (p.slices > 1 && ws_bytes < wd_bytes + p.slices * M * N * 4) p = {p.bt, 1, K};   // a short workspace costs the split, not the path
     float *wd = static_cast<float *>(ws);

@@ -65,13 +65,13 @@ static int launch_gemm_small_mf(const T *x, const uint8_t *packed, const AbsmaxV
     return check_launch("matmul_4bit(small split-K reduce)");
 }
 
-// Returns 1 when the kernel cannot serve the call (no workspace for the partials and K too long for one slice).
+// Returns MBNB_NOT_APPLICABLE when the kernel cannot serve the call (no workspace for the partials and K too long for one slice).
 template <typename T, typename OutT, bool NESTED>
 int launch_gemm_small(const T *x, const uint8_t *packed, const AbsmaxView &am, const T *bias, OutT *out, int64_t M, int64_t N, int64_t K,
                       int64_t K_weight, int qt, int bs_shift, float *ws, int64_t ws_bytes, hipStream_t st) {
     SmallPlan plan = gemm_small_plan(M, N, K);
     if (plan.slices > 1 && (ws == nullptr || ws_bytes < plan.slices * M * N * 4 || (reinterpret_cast<uintptr_t>(ws) & 15))) {
-        if (K / 256 > 8) return 1;
+        if (K / 256 > 8) return MBNB_NOT_APPLICABLE;
         plan = SmallPlan{1, 1};
     }
 #define MBNB_SMALL(MF, NF) return launch_gemm_small_mf<T, OutT, NESTED, MF, NF>(x, packed, am, bias, out, M, N, K, K_weight, qt, bs_shift, ws, ws_bytes, plan.slices, st)

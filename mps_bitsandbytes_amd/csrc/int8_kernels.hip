@@ -722,7 +722,7 @@ static int launch_linear_int8(const void *X, int64_t M, int64_t K, const int8_t 
         if (M > 32 && M <= 256) {
             // 32 < M <= 256: weight operand decoded registers -> registers (gemm_small8.h); 1 = does not apply
             const int rc = launch_gemm_small8<T, WF>(x, reinterpret_cast<const uint8_t *>(W), scales, b, o, M, N, K, ws, ws_bytes, st);
-            if (rc != 1) return rc;
+            if (rc != MBNB_NOT_APPLICABLE) return rc;
         }
         if (M >= 1 && M <= 64 && (K % 128 == 0) && (((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(W)) & 15) == 0)) {
             const unsigned grid = (unsigned)((N + 15) / 16);
@@ -801,10 +801,10 @@ int linear8_dense_path(const void *, int, int64_t, int64_t, const void *, const 
                        hipStream_t);
 
 int linear_int8_dispatch(const void *X, int dtype, int64_t M, int64_t K, const int8_t *W, const float *scales,
-                         int64_t N, const void *bias, void *out, void *workspace, int64_t ws_bytes, hipStream_t st) {
-    {   // large M: dequantise once into the workspace + dense GEMM (gemm_dense.hip); 1 = does not apply
+                         int64_t N, const void *bias, void *out, void *workspace, int64_t ws_bytes, bool fused_only, hipStream_t st) {
+    if (!fused_only) {   // large M: dequantise once into the workspace + dense GEMM (gemm_dense.hip)
         const int rc = linear8_dense_path(X, dtype, M, K, W, scales, N, false, bias, out, workspace, ws_bytes, st);
-        if (rc != 1) return rc;
+        if (rc != MBNB_NOT_APPLICABLE) return rc;
     }
     float *ws = static_cast<float *>(workspace);
     switch (dtype) {
@@ -816,10 +816,10 @@ int linear_int8_dispatch(const void *X, int dtype, int64_t M, int64_t K, const i
 
 // LinearFP8.forward / matmul_fp8_e4m3 (functional.py:796-807): the same W8A16 kernels with the FP8 byte decoder
 int linear_fp8_dispatch(const void *X, int dtype, int64_t M, int64_t K, const uint8_t *W, const float *scales, int64_t N,
-                        const void *bias, void *out, void *workspace, int64_t ws_bytes, hipStream_t st) {
-    {
+                        const void *bias, void *out, void *workspace, int64_t ws_bytes, bool fused_only, hipStream_t st) {
+    if (!fused_only) {
         const int rc = linear8_dense_path(X, dtype, M, K, W, scales, N, true, bias, out, workspace, ws_bytes, st);
-        if (rc != 1) return rc;
+        if (rc != MBNB_NOT_APPLICABLE) return rc;
     }
     float *ws = static_cast<float *>(workspace);
     const int8_t *w = reinterpret_cast<const int8_t *>(W);

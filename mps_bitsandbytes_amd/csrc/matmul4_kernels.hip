@@ -339,7 +339,7 @@ static int launch_matmul4(const void *A, int64_t M, int64_t K, const uint8_t *pa
         if (fast_layout && small_ok) {
             // 64 < M <= 256: weights decoded from registers to registers, activations by LDS-DMA (gemm_small.h)
             const int rc = launch_gemm_small<T, OutT, NESTED>(x, packed, am, b, o, M, N, K, K_weight, QT, ilog2(blocksize), ws, ws_bytes, st);
-            if (rc != 1) return rc;
+            if (rc != MBNB_NOT_APPLICABLE) return rc;
         }
         if (fast_layout && blocksize == 64 && (K_weight % 256 == 0) && gemm_mid_shape(M, N, K)) {
             // mid-sized batches: 128 x 64 tiles on the LDS-DMA pipeline, K split over the caller's workspace when given
@@ -496,10 +496,10 @@ int matmul_4bit_dispatch(const void *A, int64_t M, int64_t K, const uint8_t *pac
     if (!fused_only) {
         const int rc = matmul_4bit_dense_path(A, M, K, packed, am, N, K_weight, blocksize, qt, w_dtype, bias, out_dtype, out, workspace,
                                               ws_bytes, st);
-        if (rc != 1) return rc;
+        if (rc != MBNB_NOT_APPLICABLE) return rc;
         if (w_dtype == MBNB_F32) {   // f32 weights: decode once + f32 MFMA GEMM (gemm_f32.hip)
             const int rf = matmul_4bit_f32_path(A, M, K, packed, am, N, K_weight, blocksize, qt, bias, out_dtype, out, workspace, ws_bytes, st);
-            if (rf != 1) return rf;
+            if (rf != MBNB_NOT_APPLICABLE) return rf;
         }
     }
     float *ws = static_cast<float *>(workspace);

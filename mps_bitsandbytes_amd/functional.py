@@ -64,8 +64,11 @@ _warned: set = set()
 
 # matmul_4bit from 256 rows and 1.5 M outputs up: let the library dequantise the weight ONCE into a transient N x K scratch (in the weight dtype)
 # and run a dense MFMA GEMM -- what the reference does for M > 512 (functional.py:753-767) -- instead of the fused kernels,
-# which decode each weight tile once per 256 rows.  False keeps the fused kernels at every M (no N x K scratch).
+# which decode each weight tile once per 256 rows.  False keeps the fused kernels at every M (no N x K scratch) in matmul_4bit,
+# linear_int8 and matmul_fp8_e4m3 alike (the FUSED_ONLY flag travels to all three entry points).  The scratch is transient:
+# N x K_weight x 2 bytes per call from torch's caching allocator (32 MB for a 4096^2 layer, ~1 GB for a 128k x 4096 head).
 DECODE_ONCE = True
+MATMUL_FUSED_ONLY = 1   # include/mbnb_hip.h MBNB_MATMUL_FUSED_ONLY: the flags word of mbnb_matmul_4bit_ex / mbnb_linear_int8_ex / mbnb_linear_fp8_ex
 
 
 def _warn_once(key: str, message: str) -> None:
@@ -567,7 +570,7 @@ def matmul_4bit(
         check(_native.lib().mbnb_matmul_4bit_ex(
             ptr(A2), M, K, ptr(packed), ctypes.byref(desc), N, K_weight, int(blocksize),
             _native.QUANT_CODE[quant_state.quant_type], w_code, ptr(bias_w), _native.DTYPE_CODE[out_dtype],
-            ptr(out), ptr(ws), ws_bytes, 0 if DECODE_ONCE else 1, stream_ptr(A.device)), "matmul_4bit")
+            ptr(out), ptr(ws), ws_bytes, 0 if DECODE_ONCE else MATMUL_FUSED_ONLY, stream_ptr(A.device)), "matmul_4bit")
     if out_dtype != compute_dtype:
         out = out.to(compute_dtype)
     return out.reshape(*orig_shape[:-1], N)
@@ -646,9 +649,41 @@ def linear_int8(input: Tensor, weight_int8: Tensor, weight_scales: Tensor, bias:
     ws_bytes = int((_native.lib().mbnb_linear_int8_workspace_bytes if DECODE_ONCE else _native.lib().mbnb_matmul_4bit_splitk_workspace_bytes)(M, N, K)) if M > 16 else 0   # split-K for mid-sized M
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes > 0 else None
     with torch.cuda.device(x.device):
-        check(_native.lib().mbnb_linear_int8_ws(ptr(x), dcode, M, K, ptr(w), ptr(s), N, ptr(b), ptr(out), ptr(ws), ws_bytes,
-                                                stream_ptr(x.device)), "linear_int8")
+        check(_native.lib().mbnb_linear_int8_ex(ptr(x), dcode, M, K, ptr(w), ptr(s), N, ptr(b), ptr(out), ptr(ws), ws_bytes,
+                                                0 if DECODE_ONCE else MATMUL_FUSED_ONLY, stream_ptr(x.device)), "linear_int8")
     return out.reshape(*input.shape[:-1], N)
+
+
+def linear_dense(input: Tensor, weight: Tensor, bias: Optional[Tensor] = None) -> Tensor:
+    """
+    ``input[..., K] @ weight[N, K]^T + bias`` on an ALREADY dequantised 16-bit weight: the dense MFMA GEMM the decode-once
+    paths run after their dequantise pass (csrc/gemm_dense.h), for callers that keep the dequantised weight -- Linear8bit's
+    cache (reference nn/linear8bit.py:70-102: `F.linear(x, self._get_weight(), bias)`).  Same slice plan, hence the same bits,
+    as ``linear_int8`` / ``matmul_4bit`` on the quantised weight at that shape.  K % 64 == 0, K >= 128.
+    """
+    _check_device(input, "linear_dense")
+    _check_device(weight, "linear_dense")
+    dtype = weight.dtype
+    dcode = dtype_code(dtype, "linear_dense")
+    N, K = weight.shape
+    if input.shape[-1] != K:
+        raise RuntimeError(f"linear_dense: input width {input.shape[-1]} does not match weight {tuple(weight.shape)}")
+    x = input.reshape(-1, K).to(dtype).contiguous()
+    M = x.shape[0]
+    w = weight.contiguous()
+    b = None if bias is None else bias.to(device=x.device, dtype=dtype).contiguous()
+    out = torch.empty(M, N, dtype=dtype, device=x.device)
+    ws_bytes = int(_native.lib().mbnb_gemm_dense_workspace_bytes(M, N, K))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes > 0 else None
+    with torch.cuda.device(x.device):
+        check(_native.lib().mbnb_gemm_dense(ptr(x), ptr(w), dcode, ptr(b), dcode, ptr(out), M, N, K, K, ptr(ws), ws_bytes, 0,
+                                            stream_ptr(x.device)), "linear_dense")
+    return out.reshape(*input.shape[:-1], N)
+
+
+def dense_path_applies(M: int, N: int, K: int) -> bool:
+    """True where ``linear_int8`` / ``matmul_4bit`` take the decode-once path (dequantise into scratch + dense GEMM)."""
+    return bool(_native.lib().mbnb_gemm_dense_applies(M, N, K, K))
 
 
 # ============================================================================= FP8 E4M3 (the reference's own format)
@@ -709,8 +744,8 @@ def matmul_fp8_e4m3(input: Tensor, weight: Tensor, weight_scales: Tensor, bias: 
     ws_bytes = int((_native.lib().mbnb_linear_int8_workspace_bytes if DECODE_ONCE else _native.lib().mbnb_matmul_4bit_splitk_workspace_bytes)(M, N, K)) if M > 16 else 0
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x2.device) if ws_bytes > 0 else None
     with torch.cuda.device(x2.device):
-        check(_native.lib().mbnb_linear_fp8(ptr(x2), dcode, M, K, ptr(w), ptr(s), N, ptr(b), ptr(out), ptr(ws), ws_bytes,
-                                            stream_ptr(x2.device)), "matmul_fp8_e4m3")
+        check(_native.lib().mbnb_linear_fp8_ex(ptr(x2), dcode, M, K, ptr(w), ptr(s), N, ptr(b), ptr(out), ptr(ws), ws_bytes,
+                                               0 if DECODE_ONCE else MATMUL_FUSED_ONLY, stream_ptr(x2.device)), "matmul_fp8_e4m3")
     out = out.reshape(*lead, N)
     return out.squeeze(0) if is_1d else out
 

@@ -19,6 +19,19 @@ from torch import nn
 from .nn import Linear4bit, Linear8bit
 
 
+_dtype_coercion_warned = False
+
+
+def _warn_dtype_coercion(name: str) -> None:
+    global _dtype_coercion_warned
+    if not _dtype_coercion_warned:
+        _dtype_coercion_warned = True
+        import warnings
+        warnings.warn(f"BitsAndBytesConfig.from_dict: the compute dtype string {name!r} parses to torch.float16, as in the "
+                      "reference (its parser tests 'float16' first, which every dtype name it accepts contains or falls back "
+                      "to); pass a torch.dtype to keep bfloat16 / float32", RuntimeWarning, stacklevel=3)
+
+
 @dataclass
 class BitsAndBytesConfig:
     """Quantization config with the field names of transformers' BitsAndBytesConfig
@@ -57,14 +70,13 @@ class BitsAndBytesConfig:
         dt = d.get('bnb_4bit_compute_dtype')
         if isinstance(dt, str):
             # Reproduces the reference exactly (integration.py:86-92): it tests 'float16' first, and 'torch.bfloat16'
-            # CONTAINS 'float16' -- so every string, 'torch.bfloat16' included, comes back as torch.float16 there.
-            # A torch.dtype value passes through unchanged.  (INTEGRATION.md §4 lists this as a reference quirk kept.)
-            if 'float16' in dt:
-                d['bnb_4bit_compute_dtype'] = torch.float16
-            elif 'bfloat16' in dt:
-                d['bnb_4bit_compute_dtype'] = torch.bfloat16
-            else:
-                d['bnb_4bit_compute_dtype'] = torch.float16
+            # CONTAINS 'float16' -- so every string, 'torch.bfloat16' and 'float32' included, comes back as torch.float16
+            # there.  Kept (a config round trip must build the same layers as the reference does), but never silently: a
+            # bf16 / f32 name that is coerced to fp16 raises a RuntimeWarning (once per process).  A torch.dtype value
+            # passes through unchanged.  INTEGRATION.md §4.
+            if 'float16' not in dt or 'bfloat16' in dt:
+                _warn_dtype_coercion(dt)
+            d['bnb_4bit_compute_dtype'] = torch.float16
         return cls(**{k: v for k, v in d.items() if k in cls.__dataclass_fields__})
 
     @property

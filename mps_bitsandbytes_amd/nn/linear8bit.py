@@ -3,8 +3,11 @@ Linear8bit — row-wise INT8 linear layer on MI355X.
 
 Public surface of the reference module (mps_bitsandbytes/nn/linear8bit.py:15-166): buffers `weight_int8` [N, K] int8
 and `weight_scales` [N] f32 (the row absmax), `from_linear`, the dequantized-weight cache API and `device`.
-The forward never materialises the dequantized weight: `functional.linear_int8` decodes the int8 rows inside the GEMM
-(skinny MFMA, split-K or the 256 x 256 LDS-DMA kernel), with the reference's dequantize_rowwise -> F.linear result.
+Forward: `functional.linear_int8` decodes the int8 rows inside the GEMM at small and mid-sized batches (skinny MFMA,
+`k_gemm_small8`, split-K).  At large batches (from 256 rows / 1.5 M outputs) the kernels are the reference's own two steps,
+dequantize_rowwise -> dense GEMM; with `use_cache` (the default, as in the reference) the dequantised weight of that step is
+KEPT in `_weight_cache` (reference :70-85) and later large-batch calls run the dense GEMM alone -- same bits as the
+uncached call, minus the dequantise pass.  `use_cache=False` re-dequantises into transient scratch on every call.
 """
 from typing import Optional
 
@@ -29,11 +32,18 @@ class Linear8bit(QuantizedModule):
         self._weight_cache: Optional[Tensor] = None
 
     def forward(self, x: Tensor) -> Tensor:
+        if self.use_cache and self.compute_dtype in (torch.float16, torch.bfloat16) and x.is_cuda:
+            K = self.weight_int8.shape[1]
+            M = x.numel() // K if K else 0
+            if F.DECODE_ONCE and F.dense_path_applies(M, self.weight_int8.shape[0], K):
+                return F.linear_dense(x, self._get_weight(), self.bias)
         return F.linear_int8(x, self.weight_int8, self.weight_scales, self.bias, dtype=self.compute_dtype)
 
-    # dequantized view for LoRA merges / debugging (reference :70-89); forward() does not use it
+    # dequantized weight, kept while use_cache is set (reference :70-89): large-batch forwards, LoRA merges, debugging
     def _get_weight(self) -> Tensor:
         cached = self._weight_cache if self.use_cache else None
+        if cached is not None and (cached.device != self.weight_int8.device or cached.dtype != self.compute_dtype):
+            cached = None     # the module was moved / re-typed since the weight was cached
         if cached is None:
             cached = F.dequantize_rowwise(self.weight_int8, self.weight_scales, dtype=self.compute_dtype)
             if self.use_cache:

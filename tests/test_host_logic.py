@@ -139,6 +139,15 @@ def test_bitsandbytes_config_mirrors_reference():
     assert bnb.BitsAndBytesConfig.from_dict(d2).bnb_4bit_compute_dtype == torch.bfloat16
     assert bnb.BitsAndBytesConfig.from_dict(dict(d, bnb_4bit_compute_dtype="float32")).bnb_4bit_compute_dtype == torch.float16
     assert bnb.BitsAndBytesConfig().quantization_method == "none"
+    # the coercion of a bf16 / f32 NAME to fp16 is kept (reference behaviour) but is never silent
+    import warnings
+    from mps_bitsandbytes_amd import integration
+    integration._dtype_coercion_warned = False
+    with pytest.warns(RuntimeWarning, match="parses to torch.float16"):
+        bnb.BitsAndBytesConfig.from_dict(dict(d, bnb_4bit_compute_dtype="torch.bfloat16"))
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")     # a float16 name is what it says: no warning
+        assert bnb.BitsAndBytesConfig.from_dict(dict(d, bnb_4bit_compute_dtype="torch.float16")).bnb_4bit_compute_dtype == torch.float16
     with pytest.raises(ValueError, match="both 4-bit and 8-bit"):
         bnb.BitsAndBytesConfig(load_in_4bit=True, load_in_8bit=True)
     with pytest.raises(ValueError, match="bnb_4bit_quant_type must be"):

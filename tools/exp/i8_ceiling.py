@@ -7,7 +7,10 @@ import mps_bitsandbytes_amd as bnb
 from mps_bitsandbytes_amd import _native
 
 dev = torch.device("cuda:0")
-lib = _native.lib()
+import ctypes
+lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "libmbnb_probe.so"))   # make -C tools
+lib.mbnb_probe_mfma.restype = ctypes.c_int64
+lib.mbnb_probe_mfma.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
 sink = torch.zeros(1, dtype=torch.float32, device=dev)
 stp = torch.cuda.current_stream().cuda_stream
 

@@ -1,10 +1,18 @@
-// probe_kernels.hip — measurement aid for bench.py's `roofline.empirical` block (not part of the reference boundary):
+// mfma_probe.hip — measurement aid for bench.py's `roofline.empirical` block.  NOT part of the product: built as
+// tools/libmbnb_probe.so (tools/Makefile; __graft_entry__.build()), loaded by bench.py / tools/exp only when present:
 // a bare MFMA loop, one wave per SIMD on every CU, so that the bench can print what the matrix pipe SUSTAINS on the box
 // it runs on (the clock the chip holds under MFMA load is well under the 2.4 GHz the spec peak assumes) next to the
 // fraction of the spec peak.
-#include "common.h"
+#include <hip/hip_runtime.h>
+#include <stdint.h>
 
-namespace mbnb {
+typedef __bf16 bf16_t;
+typedef bf16_t bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
 
 template <bool I8>
 __global__ __launch_bounds__(256) void k_probe_mfma(int iters, float *sink, uint32_t seed) {
@@ -44,10 +52,16 @@ __global__ __launch_bounds__(256) void k_probe_mfma(int iters, float *sink, uint
     if (s == 123.456f) sink[0] = s;
 }
 
-int probe_mfma_dispatch(int kind, int iters, float *sink, hipStream_t st) {
+}  // namespace
+
+// Launches the loop on `stream` (256 workgroups x 4 waves, `iters` iterations of four MFMAs: kind 0 v_mfma_f32_32x32x16_bf16,
+// kind 1 v_mfma_i32_32x32x32_i8) and returns the number of MFMA wave-instructions issued (> 0), or <= 0 on failure.  The
+// caller times it: sustained rate = return value * 32768 (bf16) or 65536 (i8) operations / time.  `sink`: 4 device bytes.
+extern "C" int64_t mbnb_probe_mfma(int kind, int iters, float *sink, void *stream) {
+    if ((kind != 0 && kind != 1) || iters <= 0 || !sink) return -1;
+    hipStream_t st = static_cast<hipStream_t>(stream);
     if (kind == 0) hipLaunchKernelGGL(k_probe_mfma<false>, dim3(256), dim3(256), 0, st, iters, sink, 7u);
     else hipLaunchKernelGGL(k_probe_mfma<true>, dim3(256), dim3(256), 0, st, iters, sink, 7u);
-    return check_launch("probe_mfma");
+    if (hipGetLastError() != hipSuccess) return -2;
+    return (int64_t)256 * 4 * 4 * iters;
 }
-
-}  // namespace mbnb
