@@ -201,6 +201,9 @@ int mbnb_matmul_int8(const int8_t *A, const int8_t *B, const float *A_scales,
 /* mbnb_matmul_4bit_ws with a flags word.  MBNB_MATMUL_FUSED_ONLY keeps the fused dequant + MFMA kernels at every M even when
  * the workspace could hold the dequantised weight (the workspace then serves split-K only); 0 = mbnb_matmul_4bit_ws. */
 #define MBNB_MATMUL_FUSED_ONLY 1
+/* MBNB_MATMUL_FUSED4: serve large blocksize-64 problems (>= 96 tiles of 256 x 256, K % 64 == 0, K_weight % 256 == 0) with the
+ * four-wave fused decode + MFMA kernel (csrc/gemm_fused4.h): one launch, no scratch, the bits of the decode-once path. */
+#define MBNB_MATMUL_FUSED4 2
 int mbnb_matmul_4bit_ex(const void *A, int64_t M, int64_t K, const uint8_t *packed,
                         const mbnb_absmax *absmax, int64_t N, int64_t K_weight, int blocksize,
                         int quant_type, int w_dtype, const void *bias, int out_dtype, void *out,

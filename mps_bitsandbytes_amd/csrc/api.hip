@@ -64,7 +64,7 @@ int dequant_absmax_dispatch(const void *, int, int64_t, int64_t, const float *, 
 int quantize_rowwise_dispatch(const void *, int, int64_t, int64_t, int8_t *, float *, hipStream_t);
 int dequantize_rowwise_dispatch(const int8_t *, const float *, int64_t, int64_t, int, void *, hipStream_t);
 int double_quant_dispatch(const void *, int, int64_t, int64_t, int8_t *, int8_t *, float *, float *, int, int, hipStream_t);
-int matmul_4bit_dispatch(const void *, int64_t, int64_t, const uint8_t *, const AbsmaxView &, int64_t, int64_t, int, int, int, const void *, int, void *, void *, int64_t, bool,
+int matmul_4bit_dispatch(const void *, int64_t, int64_t, const uint8_t *, const AbsmaxView &, int64_t, int64_t, int, int, int, const void *, int, void *, void *, int64_t, int,
                          hipStream_t);
 int quantize_fp8_dispatch(const void *, int, int64_t, int64_t, uint8_t *, float *, hipStream_t);
 int dequantize_fp8_dispatch(const uint8_t *, const float *, int64_t, int64_t, int, void *, hipStream_t);
@@ -231,7 +231,7 @@ int mbnb_double_quant(const void *A, int dtype, int64_t rows, int64_t cols, int8
 int mbnb_matmul_4bit_ex(const void *A, int64_t M, int64_t K, const uint8_t *packed, const mbnb_absmax *absmax, int64_t N,
                         int64_t K_weight, int blocksize, int quant_type, int w_dtype, const void *bias, int out_dtype,
                         void *out, void *workspace, int64_t workspace_bytes, int flags, void *stream) {
-    if (flags & ~MBNB_MATMUL_FUSED_ONLY) return fail(MBNB_ERR_ARG, "matmul_4bit: unknown flags 0x%x", flags);
+    if (flags & ~(MBNB_MATMUL_FUSED_ONLY | MBNB_MATMUL_FUSED4)) return fail(MBNB_ERR_ARG, "matmul_4bit: unknown flags 0x%x", flags);
     if (!dtype_ok(w_dtype) || !dtype_ok(out_dtype) || !qt_ok(quant_type))
         return fail(MBNB_ERR_ARG, "matmul_4bit: bad dtype/quant_type");
     if (M < 0 || N < 0 || K < 0) return fail(MBNB_ERR_ARG, "matmul_4bit: negative size");
@@ -245,8 +245,7 @@ int mbnb_matmul_4bit_ex(const void *A, int64_t M, int64_t K, const uint8_t *pack
     if (!A || !packed || !out) return fail(MBNB_ERR_ARG, "matmul_4bit: NULL pointer");
     // the split-K workspace travels down the dispatch as an argument (no per-call state is kept anywhere)
     return matmul_4bit_dispatch(A, M, K, packed, v, N, K_weight, blocksize, quant_type, w_dtype, bias, out_dtype, out,
-                                workspace, workspace ? workspace_bytes : 0, (flags & MBNB_MATMUL_FUSED_ONLY) != 0,
-                                static_cast<hipStream_t>(stream));
+                                workspace, workspace ? workspace_bytes : 0, flags, static_cast<hipStream_t>(stream));
 }
 
 int mbnb_matmul_4bit_ws(const void *A, int64_t M, int64_t K, const uint8_t *packed, const mbnb_absmax *absmax, int64_t N,

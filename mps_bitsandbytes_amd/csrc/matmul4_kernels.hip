@@ -34,6 +34,8 @@ bool gemm_small_shape(int64_t M, int64_t N, int64_t K, int64_t K_weight);
 template <typename T, typename OutT, bool NESTED>
 int launch_gemm_small(const T *, const uint8_t *, const AbsmaxView &, const T *, OutT *, int64_t, int64_t, int64_t, int64_t, int, int, float *,
                       int64_t, hipStream_t);
+int matmul_4bit_fused4_path(const void *, int64_t, int64_t, const uint8_t *, const AbsmaxView &, int64_t, int64_t, int, int, int, const void *, int, void *,
+                            hipStream_t);
 int matmul_4bit_f32_path(const void *, int64_t, int64_t, const uint8_t *, const AbsmaxView &, int64_t, int64_t, int, int, const void *, int, void *, void *, int64_t, hipStream_t);
 int matmul_4bit_dense_path(const void *, int64_t, int64_t, const uint8_t *, const AbsmaxView &, int64_t, int64_t, int, int, int, const void *,
                            int, void *, void *, int64_t, hipStream_t);
@@ -491,8 +493,13 @@ extern "C" int mbnb_debug_read_stamps(unsigned long long *host_out) {
 
 int matmul_4bit_dispatch(const void *A, int64_t M, int64_t K, const uint8_t *packed, const AbsmaxView &am, int64_t N,
                          int64_t K_weight, int blocksize, int qt, int w_dtype, const void *bias, int out_dtype,
-                         void *out, void *workspace, int64_t ws_bytes, bool fused_only, hipStream_t st) {
-    // large M: decode the weight once into the workspace, then the dense MFMA GEMM (gemm_dense.hip); 1 = does not apply
+                         void *out, void *workspace, int64_t ws_bytes, int flags, hipStream_t st) {
+    const bool fused_only = (flags & MBNB_MATMUL_FUSED_ONLY) != 0;
+    if (flags & MBNB_MATMUL_FUSED4) {   // the four-wave fused kernel (gemm_fused4.hip) where it applies
+        const int rc = matmul_4bit_fused4_path(A, M, K, packed, am, N, K_weight, blocksize, qt, w_dtype, bias, out_dtype, out, st);
+        if (rc != MBNB_NOT_APPLICABLE) return rc;
+    }
+    // large M: decode the weight once into the workspace, then the dense MFMA GEMM (gemm_dense.hip)
     if (!fused_only) {
         const int rc = matmul_4bit_dense_path(A, M, K, packed, am, N, K_weight, blocksize, qt, w_dtype, bias, out_dtype, out, workspace,
                                               ws_bytes, st);
