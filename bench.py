@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """
-bench.py — throughput of the fused NF4 dequant + matmul hot path on MI355X.
+bench.py — throughput of the NF4 dequant + matmul hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: N child ranks are started)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -11,19 +11,23 @@ W untimed warm-up steps, then R = 5 repetitions of the K-step loop, each bracket
 sides and reduced with MAX over ranks; `value` and `ms_per_step` come from the MEDIAN repetition, and the kernel's
 launch duration (`roofline.kernel_us`) from HIP events recorded inside that same repetition on the launching stream.
 
-One "step" = one pass of the hot path over one batch: Linear4bit-style fused NF4 dequant + matmul,
-weight 4096x4096 (bf16-origin, blocksize 64), M = 4096 rows per GPU, bf16 activations, inputs
-resident in HBM.  With N > 1 the weight is replicated, every rank owns 4096 rows of a global
+One "step" = one pass of the hot path over one batch: Linear4bit-style matmul_4bit on an NF4 weight
+4096x4096 (bf16-origin, blocksize 64), M = 4096 rows per GPU, bf16 activations, inputs resident in HBM.  At this M the
+library dequantises the weight ONCE into a transient scratch and runs a dense MFMA GEMM (two launches per step, as the
+reference does above M = 512); the line says which launches served the step (config.kernel, roofline.launches).  With N > 1 the weight is replicated, every rank owns 4096 rows of a global
 batch of 4096*N (BASELINE configs[4] at N = 8: M = 32768) and the step ends with an RCCL
 all-gather of the output shards over xGMI (weak scaling).
 
 Rank 0 prints ONE JSON line: metric/value per the driver contract plus
-  "roofline"     the dominant kernel (k_gemm_decode, MFMA-bound): algorithmic flops per launch /
-                 average launch duration measured with HIP events on the launching stream
+  "roofline"     the OPERATION (the whole step, every launch of one matmul call; MFMA-bound): algorithmic flops / step duration
+                 measured with HIP events on the launching stream; `dominant_kernel` carries the largest launch alone
   "cpu_baseline" the CPU oracle (a port of the reference's CPU path) timed on this box's host
                  cores on a bounded row-sample of the same workload
   "gemv"         the M = 1 decode shape of the metric (HBM-bound), rotating over 64 distinct
                  layers (605 MB > 256 MB Infinity Cache), with its own roofline fraction.
+  "secondary"    (default workload, N = 1) the other BASELINE GPU configs as complete lines of their own: nf4dq_ffn (configs[2]),
+                 int8_4096 (configs[3]), nf4_m1 (configs[1] stand-alone), each with roofline, traffic and cpu_baseline
+  "no_prewarm"   the same K steps timed before the disclosed time-based pre-warm (cold clock)
 """
 import argparse
 import json
@@ -56,6 +60,7 @@ def parse():
                     "with --no-gather and the default these are the three curves of SURVEY 8e")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemv", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="default workload at N = 1: skip the secondary lines (BASELINE configs 2, 3 and stand-alone 1)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--prewarm-ms", type=float, default=400.0, help="untimed, time-based load before the warm-up steps")
     ap.add_argument("--reps", type=int, default=5, help="repetitions of the K-step loop; the median one is reported")
@@ -305,13 +310,12 @@ def cpu_baseline_int8(args, M, N, K):
     """matmul_int8 on the host cores: the oracle's restatement of functional.py:788-793 on a row sample of the workload."""
     import oracle
     threads = oracle.num_threads()
-    gcpu = torch.Generator()
-    gcpu.manual_seed(4321)
+    from mps_bitsandbytes_amd import synthetic
     rows = 256
-    A = torch.randint(-127, 128, (rows, K), generator=gcpu, dtype=torch.int8)
-    B = torch.randint(-127, 128, (K, N), generator=gcpu, dtype=torch.int8)
-    sa = torch.rand(rows, generator=gcpu) + 0.5
-    sb = torch.rand(N, generator=gcpu) + 0.5
+    A = synthetic.int8_tensor((rows, K), seed=4321)
+    B = synthetic.int8_tensor((K, N), seed=1234)
+    sa = synthetic.normal((rows,), torch.float32, seed=77).abs() + 0.5
+    sb = synthetic.normal((N,), torch.float32, seed=78).abs() + 0.5
     oracle.matmul_int8(A[:16], B, sa[:16], sb, torch.float16)
     reps, spent = 0, 0.0
     while spent < min(args.cpu_seconds, 10.0) and reps < 256:
@@ -398,46 +402,23 @@ def median_rep(reps):
     return reps[order[len(order) // 2]]
 
 
-def main():
-    args = parse()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        spawn_ranks(args)   # does not return
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        print(json.dumps({"error": f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU"}))
-        sys.exit(2)
-    distributed = world > 1
-    if not torch.cuda.is_available():
-        print(json.dumps({"error": "no GPU visible; bench.py measures the HIP path only", "rank": rank, "world": world}), flush=True)
-        sys.exit(2)
-    # BENCH_REHEARSE=1: every rank uses cuda:0 and the gloo backend -- lets the N > 1 code path be exercised on a
-    # one-GPU box (RCCL refuses two ranks on one device); numbers from such a run mean nothing.
-    rehearse = os.environ.get("BENCH_REHEARSE") == "1"
-    if rehearse:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    if distributed:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearse:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+class Ctx:
+    """what measure() needs of the process: rank / world, device, torch.distributed (or None), the timer"""
+    pass
 
+
+def gen_normal(synthetic, shape, dt, seed, std, dev):
+    """bench inputs from the repo's counter-based PRNG, generated on the device (synthetic.normal_device: bit-identical
+    to synthetic.normal on the host)"""
+    return synthetic.normal_device(shape, dt, seed=seed, std=std, device=dev)
+
+
+def measure(args, wl, ctx):
+    """One workload -> the dict of its bench line (rank 0; other ranks take part in the timed region and return their copy)."""
     import mps_bitsandbytes_amd as bnb
     from mps_bitsandbytes_amd import _native, synthetic
     from mps_bitsandbytes_amd.sharding import ChunkedGather, row_shard
-    _native.lib()  # fail loudly when the HIP library is missing
-
-    wl = args.workload
-    if wl in ("embed4", "embed8", "outlier", "w8a16", "fp8"):
-        if rank == 0:
-            print(json.dumps(bench_nn(args, wl, dev, bnb, synthetic)))
-        return
+    world, rank, dev, dist, distributed, rehearse = ctx.world, ctx.rank, ctx.dev, ctx.dist, ctx.distributed, ctx.rehearse
     if wl == "nf4_m4096":
         M, N, K, dt, compress, name = 4096, 4096, 4096, torch.bfloat16, False, "bf16"
     elif wl == "nf4dq_ffn":
@@ -449,14 +430,9 @@ def main():
 
     M_global = M * world
     s_row, e_row = row_shard(M_global, rank, world)
-    gw = torch.Generator(device=dev)
-    gw.manual_seed(1234)            # the replicated weight: the same on every rank
-    g = torch.Generator(device=dev)
-    g.manual_seed(4321 + rank)      # this rank's rows of the global batch
-
     out = {"metric": None, "value": None, "unit": None, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": name,
-           "data": "synthetic"}
+           "data": "synthetic (repo PRNG: synthetic.py, weights seed 1234 + layer, activations seed 4321 + rank)"}
     timer = Timer(distributed, dist, "cpu" if rehearse else dev)
     reps_n = max(1, args.reps)
 
@@ -464,15 +440,14 @@ def main():
     modes = {}        # name -> (step, finish)
     if wl in ("nf4_m4096", "nf4dq_ffn", "nf4_m1"):
         std = 1.0 if wl != "nf4dq_ffn" else 0.02
-        W = (torch.randn(N, K, generator=gw, device=dev, dtype=torch.float32) * std).to(dt)
         if wl == "nf4_m1":
             # rotate over 64 distinct layers so the weights come from HBM, not the Infinity Cache
             layers = []
             for i in range(64):
-                Wi = (torch.randn(N, K, generator=gw, device=dev, dtype=torch.float32)).to(dt)
+                Wi = gen_normal(synthetic, (N, K), dt, 1234 + i, 1.0, dev)
                 layers.append(bnb.quantize_nf4(Wi, blocksize=64))
                 del Wi
-            X = torch.randn(1, K, generator=g, device=dev, dtype=torch.float32).to(dt)
+            X = gen_normal(synthetic, (1, K), dt, 4321 + rank, 1.0, dev)
 
             def eager_pass():
                 for p, st in layers:
@@ -492,11 +467,12 @@ def main():
             torch.cuda.current_stream().wait_stream(side)
             modes["main"] = (m1_graph.replay, None)
             flops_per_step = 2.0 * N * K * 64
-            bytes_per_launch = N * K // 2 + N * (K // 64) * 4 + K * 2 + N * 2   # SURVEY §8d: 9 453 568 B
+            bytes_per_launch = N * K // 2 + N * (K // 64) * 4 + K * 2 + N * 2   # SURVEY 8d: 9 453 568 B
         else:
+            W = gen_normal(synthetic, (N, K), dt, 1234, std, dev)     # the replicated weight: the same on every rank
             packed, state = bnb.quantize_nf4(W, blocksize=64, compress_statistics=compress)
             del W
-            X = torch.randn(e_row - s_row, K, generator=g, device=dev, dtype=torch.float32).to(dt)
+            X = gen_normal(synthetic, (e_row - s_row, K), dt, 4321 + rank, 1.0, dev)   # this rank's rows of the global batch
 
             def gemm_step():
                 bnb.matmul_4bit(X, packed, state)
@@ -510,7 +486,7 @@ def main():
                 #   overlapped  async all-gather of step i (RCCL's stream) under the GEMM of step i+1 (two result buffers)
                 #   chunked     inside ONE step: the rank's rows in c chunks, GEMM of chunk i+1 under the gather of chunk i
                 gathered = [torch.empty(M_global, N, dtype=dt, device=dev) for _ in range(2)]
-                pending = [None, None]
+                pending = [None, None]     # (work handle, the shard it reads): the shard stays referenced until its gather is waited for
                 counter = [0]
 
                 def overlapped_step():
@@ -518,13 +494,13 @@ def main():
                     i = counter[0] & 1
                     counter[0] += 1
                     if pending[i] is not None:
-                        pending[i].wait()
-                    pending[i] = dist.all_gather_into_tensor(gathered[i], y, async_op=True)
+                        pending[i][0].wait()
+                    pending[i] = (dist.all_gather_into_tensor(gathered[i], y, async_op=True), y)
 
                 def overlapped_finish():
                     for i in range(2):
                         if pending[i] is not None:
-                            pending[i].wait()
+                            pending[i][0].wait()
                             pending[i] = None
 
                 def sync_step():
@@ -539,10 +515,13 @@ def main():
                 modes["chunked"] = (lambda: cg.step(X), cg.finish)
                 modes["main"] = modes["sync"] if args.sync_gather else modes["overlapped"]
     else:
-        A = torch.randint(-127, 128, (M, K), generator=g, device=dev, dtype=torch.int8)
-        B = torch.randint(-127, 128, (K, N), generator=g, device=dev, dtype=torch.int8)
-        sa = torch.rand(M, generator=g, device=dev) + 0.5
-        sb = torch.rand(N, generator=g, device=dev) + 0.5
+        # A, B ~ N(0, 1) fp16, quantised by quantize_rowwise (A by row, B by column)
+        A16 = gen_normal(synthetic, (M, K), dt, 4321 + rank, 1.0, dev)
+        B16 = gen_normal(synthetic, (K, N), dt, 1234, 1.0, dev)
+        A, sa = bnb.quantize_rowwise(A16)
+        Bt, sb = bnb.quantize_rowwise(B16.t().contiguous())
+        B = Bt.t().contiguous()          # [K, N] as the reference passes it
+        del A16, B16, Bt
 
         def step():
             bnb.matmul_int8(A, B, sa, sb, torch.float16)
@@ -550,6 +529,12 @@ def main():
         flops_per_step = 2.0 * M * N * K
 
     step, finish = modes["main"]
+    # the driver's protocol WITHOUT the time-based pre-warm, measured first (cold clock): W warm-up steps, then K timed steps
+    for _ in range(args.warmup):
+        step()
+    if finish is not None:
+        finish()
+    cold = timer.run(step, finish, args.steps, 1)[0]
     prewarm_steps = timer.prewarm(step, finish, args.prewarm_ms) if args.prewarm_ms > 0 else 0
     for _ in range(args.warmup):
         step()
@@ -576,7 +561,7 @@ def main():
                 f_()
             curves[cname] = median_rep(timer.run(s_, f_, args.steps, min(reps_n, 3)))
 
-    # device-side duration of one launch: the events of the median repetition (for N > 1: of the gather-free curve)
+    # device-side duration of one step: the events of the median repetition (for N > 1: of the gather-free curve)
     if do_gather:
         kern_ms = curves["gemm_only"][1] / args.steps
     elif wl == "nf4_m1":
@@ -591,11 +576,17 @@ def main():
     if do_gather:
         par += (", all-gather of outputs (RCCL, blocking)" if args.sync_gather
                 else ", all-gather of outputs (RCCL, async: the gather of step i overlaps the GEMM of step i+1)")
-    out["config"] = {"workload": {"nf4_m4096": "Linear4bit-style fused NF4 dequant+matmul, weight 4096x4096 bf16-origin bs64, M=4096 rows per GPU",
-                                  "nf4dq_ffn": "fused NF4 + double-quant absmax, weight 11008x4096 bf16 bs64, M=4096",
-                                  "int8_4096": "rowwise INT8 matmul_int8 4096x4096x4096 on int8 MFMA",
+    two_launch = kernel_name.startswith("dequant+dense")
+    how = ("dequantize_4bit ONCE into a transient scratch + dense MFMA GEMM (two launches per step; the reference's own two steps above M = 512)"
+           if two_launch else "one fused dequant + MFMA launch per step")
+    out["config"] = {"workload": {"nf4_m4096": f"Linear4bit-style NF4 matmul_4bit, weight 4096x4096 bf16-origin bs64, M=4096 rows per GPU: {how}",
+                                  "nf4dq_ffn": f"NF4 + double-quant absmax matmul_4bit, weight 11008x4096 bf16 bs64, M=4096: {how}",
+                                  "int8_4096": "rowwise INT8 matmul_int8 4096x4096x4096 on int8 MFMA (A by row, B [K, N] by column)",
                                   "nf4_m1": "fused NF4 dequant+GEMV, weight 4096x4096 fp16 bs64, M=1, rotating over 64 layers (one HIP graph of the 64 launches per step)"}[wl],
                      "global_rows": M_global, "rows_per_gpu": M, "N": N, "K": K, "parallelism": par, "kernel": kernel_name}
+    out["no_prewarm"] = {"ms_per_step": round(cold[0] / args.steps * 1e3, 5),
+                         "note": "the same K steps after the W warm-up steps only, BEFORE the time-based pre-warm (cold clock): what a driver-side "
+                                 "timer around a fresh process sees without the disclosed pre-warm"}
     traffic = {}
     prof = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(prof):
@@ -608,6 +599,7 @@ def main():
         out["metric"] = "effective GB/s, fused NF4 dequant+GEMV 4096x4096 M=1 (HBM, 64 rotating layers)"
         out["value"] = round(bytes_per_launch * 64 * world / (elapsed / args.steps) / 1e9, 2)
         out["unit"] = "GB/s"
+        out["no_prewarm"]["value"] = round(bytes_per_launch * 64 * world / (cold[0] / args.steps) / 1e9, 2)
         out["roofline"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                            "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": traffic.get("k_gemv4_bytes_per_launch"),
                            "kernel_us": round(kern_ms * 1e3, 3)}
@@ -615,30 +607,49 @@ def main():
         tflops = total_flops / (elapsed / args.steps) / 1e12
         peak = PEAK_TFLOPS[name]
         kern_tflops = flops_per_step / (kern_ms * 1e-3) / 1e12
-        out["metric"] = ("effective bf16 TFLOPS, fused NF4 dequant+matmul 4096x4096 @ M=4096" if wl == "nf4_m4096"
-                         else f"effective TFLOPS, {wl}")
+        unit = "TOP/s" if wl == "int8_4096" else "TFLOP/s"
+        out["metric"] = {"nf4_m4096": "effective bf16 TFLOPS, NF4 dequant+matmul 4096x4096 @ M=4096 (" + ("dequantise-once + dense GEMM, two launches" if two_launch else "one fused launch") + ")",
+                         "nf4dq_ffn": "effective bf16 TFLOPS, NF4 + double-quant matmul 11008x4096 @ M=4096 (" + ("dequantise-once + dense GEMM, two launches" if two_launch else "one fused launch") + ")",
+                         "int8_4096": "effective int8 TOPS, rowwise matmul_int8 4096x4096x4096"}[wl]
         out["value"] = round(tflops, 2)
-        out["unit"] = "TFLOP/s"
+        out["unit"] = unit
+        out["no_prewarm"]["value"] = round(total_flops / (cold[0] / args.steps) / 1e12, 2)
         for cname, (el, _) in curves.items():
-            out[cname] = {"value": round(total_flops / (el / args.steps) / 1e12, 2), "unit": "TFLOP/s",
+            out[cname] = {"value": round(total_flops / (el / args.steps) / 1e12, 2), "unit": unit,
                           "ms_per_step": round(el / args.steps * 1e3, 5)}
         if do_gather:
             out["curves_note"] = ("gemm_only = no exchange; sync = blocking all-gather per step; overlapped = async gather of step i "
                                   f"under the GEMM of step i+1; chunked = {args.chunks} row chunks per step, GEMM of chunk i+1 under "
                                   "the gather of chunk i (each chunk fills only 1/c of the 256 CUs at this shape)")
-        tkey = {"nf4_m4096": "k_gemm256p_bytes_per_launch", "int8_4096": "k_gemm_i8_bytes_per_launch"}.get(wl)
-        out["roofline"] = {"bound": "mfma", "achieved": round(kern_tflops, 2), "peak": peak, "unit": "TFLOP/s",
-                           "frac": round(kern_tflops / peak, 4), "traffic": traffic.get(tkey) if tkey else None,
+        # The roofline object describes the OPERATION (the whole step: every launch of it), per GPU: algorithmic flops / step
+        # duration by HIP events on the launching stream.  `traffic`: PMC bytes of the step's launches (profiles/traffic.json).
+        tkey = {"nf4_m4096": "nf4_m4096_step_bytes", "nf4dq_ffn": "nf4dq_ffn_step_bytes", "int8_4096": "int8_4096_step_bytes"}[wl]
+        out["roofline"] = {"bound": "mfma", "scope": "the whole step (all launches of one matmul call)", "achieved": round(kern_tflops, 2),
+                           "peak": peak, "unit": unit, "frac": round(kern_tflops / peak, 4), "traffic": traffic.get(tkey),
                            "kernel_us": round(kern_ms * 1e3, 2),
-                           "kernel_us_note": "HIP events around the K launches of the median repetition / K (includes the inter-launch boundary)"}
-        if kernel_name.startswith("dequant+dense") and wl in ("nf4_m4096", "nf4dq_ffn"):
-            # A step is two launches here: dequantize_4bit into the scratch, then k_gemm_dense.  The roofline object is the
-            # DOMINANT kernel's: k_gemm_dense timed on its own (same operands, same stream, events around K launches), with
-            # the dequantise pass and the whole step beside it.
-            lib, code, sp = _native.lib(), _native.DTYPE_CODE[dt], _native.stream_ptr(dev)
+                           "kernel_us_note": "HIP events around the K steps of the median repetition / K (includes the inter-launch boundaries)"}
+        lib, sp = _native.lib(), _native.stream_ptr(dev)
+        st_ = torch.cuda.current_stream()
+
+        def ev_us(fn):
+            vals = []
+            for _ in range(reps_n):
+                for _ in range(3):
+                    fn()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(st_)
+                for _ in range(args.steps):
+                    fn()
+                e1.record(st_)
+                e1.synchronize()
+                vals.append(e0.elapsed_time(e1) / args.steps * 1e3)
+            return sorted(vals)[len(vals) // 2]
+
+        if two_launch and wl in ("nf4_m4096", "nf4dq_ffn"):
+            # the step's two launches on their own (same operands, same stream, events around K launches)
+            code = _native.DTYPE_CODE[dt]
             Wd = bnb.dequantize_4bit(packed, state)
             Yd = torch.empty(M, N, dtype=dt, device=dev)
-            st_ = torch.cuda.current_stream()
 
             def dense_only():
                 rc = lib.mbnb_gemm_dense(X.data_ptr(), Wd.data_ptr(), code, None, code, Yd.data_ptr(), M, N, K, K, None, 0, 1, sp)
@@ -648,30 +659,20 @@ def main():
             def dequant_only():
                 bnb.dequantize_4bit(packed, state, out=Wd)
 
-            def ev_us(fn):
-                vals = []
-                for _ in range(reps_n):
-                    for _ in range(3):
-                        fn()
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record(st_)
-                    for _ in range(args.steps):
-                        fn()
-                    e1.record(st_)
-                    e1.synchronize()
-                    vals.append(e0.elapsed_time(e1) / args.steps * 1e3)
-                return sorted(vals)[len(vals) // 2]
-
             dense_us, deq_us = ev_us(dense_only), ev_us(dequant_only)
             assert torch.equal(Yd, bnb.matmul_4bit(X, packed, state)), "dense-only launch differs from the step's output"
             d_tflops = flops_per_step / (dense_us * 1e-6) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": "k_gemm_dense", "achieved": round(d_tflops, 2), "peak": peak, "unit": "TFLOP/s",
-                               "frac": round(d_tflops / peak, 4), "traffic": traffic.get("k_gemm_dense_bytes_per_launch") if wl == "nf4_m4096" else None,
-                               "kernel_us": round(dense_us, 2),
-                               "kernel_us_note": "k_gemm_dense alone: HIP events around K launches on the launching stream / K, median repetition",
-                               "step_us": round(kern_ms * 1e3, 2), "dequantize_us": round(deq_us, 2),
-                               "step_frac": round(kern_tflops / peak, 4),
-                               "step_note": "a step = dequantize_4bit into the scratch + k_gemm_dense; step_frac = algorithmic flops / step_us / peak"}
+            out["roofline"]["launches"] = ["k_dequantize_4bit (N x K_weight 16-bit values into the scratch)", "k_gemm_dense"]
+            out["roofline"]["dominant_kernel"] = {
+                "kernel": "k_gemm_dense", "kernel_us": round(dense_us, 2), "achieved": round(d_tflops, 2), "frac": round(d_tflops / peak, 4),
+                "traffic": traffic.get("k_gemm_dense_bytes_per_launch") if wl == "nf4_m4096" else traffic.get("nf4dq_ffn_gemm_dense_bytes_per_launch"),
+                "note": "k_gemm_dense ALONE on the already dequantised weight (HIP events around K launches / K): NOT the operation the metric names"}
+            out["roofline"]["dequantize_us"] = round(deq_us, 2)
+            del Wd, Yd
+        if wl == "int8_4096":
+            out["roofline"]["launches"] = ["k_transpose_i8 (B [K, N] -> [N, K] into the workspace)", "k_gemm_dense<I8>"] if "dense" in kernel_name else [kernel_name]
+            out["roofline"]["dominant_kernel"] = {"kernel": kernel_name, "traffic": traffic.get("k_gemm_i8_bytes_per_launch"),
+                                                  "note": "PMC bytes of the GEMM launch alone"}
 
     if args.verify and do_gather:
         # gathered == unsharded: rank 0 rebuilds every rank's rows and runs the whole batch through the same kernel
@@ -685,10 +686,8 @@ def main():
         if rank == 0:
             xs = []
             for r in range(world):
-                gr = torch.Generator(device=dev)
-                gr.manual_seed(4321 + r)
                 sr, er = row_shard(M_global, r, world)
-                xs.append(torch.randn(er - sr, K, generator=gr, device=dev, dtype=torch.float32).to(dt))
+                xs.append(gen_normal(synthetic, (er - sr, K), dt, 4321 + r, 1.0, dev))
             ref = bnb.matmul_4bit(torch.cat(xs), packed, state)
             ok = bool(torch.equal(full, ref)) and bool(torch.equal(chunked_full.reshape(M_global, N), ref))
             del xs, ref
@@ -700,10 +699,10 @@ def main():
             # the M = 1 half of the metric: HBM-bound decode shape, 64 rotating layers
             layers = []
             for i in range(64):
-                Wi = torch.randn(N, K, generator=g, device=dev, dtype=torch.float32).to(dt)
+                Wi = gen_normal(synthetic, (N, K), dt, 2000 + i, 1.0, dev)
                 layers.append(bnb.quantize_nf4(Wi, blocksize=64))
                 del Wi
-            x1 = torch.randn(1, K, generator=g, device=dev, dtype=torch.float32).to(dt)
+            x1 = gen_normal(synthetic, (1, K), dt, 4320, 1.0, dev)
 
             def gemv_pass():
                 for p, st in layers:
@@ -754,8 +753,8 @@ def main():
             # batch sizes between the two metric shapes (the reference's native path serves M <= 512): one HIP graph of
             # 8 calls per M, same weight; which kernel served it is recorded next to the time
             sweep = []
-            for Ms in (2, 16, 64, 128, 256, 1024):
-                xs_ = torch.randn(Ms, K, generator=g, device=dev, dtype=torch.float32).to(dt)
+            for Ms in (2, 16, 64, 128, 256, 512, 1024):
+                xs_ = gen_normal(synthetic, (Ms, K), dt, 5000 + Ms, 1.0, dev)
                 gr = torch.cuda.CUDAGraph()
                 side = torch.cuda.Stream()
                 side.wait_stream(torch.cuda.current_stream())
@@ -806,12 +805,84 @@ def main():
                     "bare_mfma_note": "v_mfma_i32_32x32x32_i8 back to back on every SIMD, nothing else: the sustained int8 matrix rate at the clock the chip holds under that load"}
         except Exception as e:  # context only
             out["roofline"]["empirical"] = {"error": str(e)[:200]}
-    if rank == 0 and not args.no_cpu_baseline and world == 1 and wl in ("nf4_m4096", "nf4dq_ffn"):
-        out["cpu_baseline"] = cpu_baseline(args, M, N, K, 64, compress, dt)
-    if rank == 0 and not args.no_cpu_baseline and world == 1 and wl == "nf4_m1":
-        out["cpu_baseline"] = cpu_baseline_gemv(args, N, K, dt)
-    if rank == 0 and not args.no_cpu_baseline and world == 1 and wl == "int8_4096":
-        out["cpu_baseline"] = cpu_baseline_int8(args, M, N, K)
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        import oracle
+        nproc = oracle.num_threads()
+        base = {"nf4_m4096": lambda: cpu_baseline(args, M, N, K, 64, compress, dt), "nf4dq_ffn": lambda: cpu_baseline(args, M, N, K, 64, compress, dt),
+                "nf4_m1": lambda: cpu_baseline_gemv(args, N, K, dt), "int8_4096": lambda: cpu_baseline_int8(args, M, N, K)}[wl]
+        out["cpu_baseline"] = base()
+        if nproc > 8:     # the host baseline at nproc threads AND at 8 threads (the build container's core count)
+            oracle.set_num_threads(8)
+            try:
+                half = argparse.Namespace(**vars(args))
+                half.cpu_seconds = max(2.0, args.cpu_seconds / 2)
+                b8 = {"nf4_m4096": lambda: cpu_baseline(half, M, N, K, 64, compress, dt), "nf4dq_ffn": lambda: cpu_baseline(half, M, N, K, 64, compress, dt),
+                      "nf4_m1": lambda: cpu_baseline_gemv(half, N, K, dt), "int8_4096": lambda: cpu_baseline_int8(half, M, N, K)}[wl]()
+                out["cpu_baseline_8_threads"] = b8
+            finally:
+                oracle.set_num_threads(nproc)
+    return out
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)   # does not return
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(json.dumps({"error": f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU"}))
+        sys.exit(2)
+    distributed = world > 1
+    if not torch.cuda.is_available():
+        print(json.dumps({"error": "no GPU visible; bench.py measures the HIP path only", "rank": rank, "world": world}), flush=True)
+        sys.exit(2)
+    # BENCH_REHEARSE=1: every rank uses cuda:0 and the gloo backend -- lets the N > 1 code path be exercised on a
+    # one-GPU box (RCCL refuses two ranks on one device); numbers from such a run mean nothing.
+    rehearse = os.environ.get("BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import mps_bitsandbytes_amd as bnb
+    from mps_bitsandbytes_amd import _native, synthetic
+    _native.lib()  # fail loudly when the HIP library is missing
+
+    wl = args.workload
+    if wl in ("embed4", "embed8", "outlier", "w8a16", "fp8"):
+        if rank == 0:
+            print(json.dumps(bench_nn(args, wl, dev, bnb, synthetic)))
+        return
+    ctx = Ctx()
+    ctx.world, ctx.rank, ctx.dev, ctx.dist, ctx.distributed, ctx.rehearse = world, rank, dev, dist, distributed, rehearse
+    out = measure(args, wl, ctx)
+    if rank == 0 and world == 1 and wl == "nf4_m4096" and not args.no_secondary:
+        # the other BASELINE GPU configs under the same clock: configs[2] (11008 x 4096 + double quant), configs[3] (int8 4096^3),
+        # configs[1] stand-alone (M = 1 over 64 rotating layers), each with its own roofline / traffic / cpu_baseline
+        sec = []
+        for w2 in ("nf4dq_ffn", "int8_4096", "nf4_m1"):
+            a2 = argparse.Namespace(**vars(args))
+            a2.cpu_seconds = min(args.cpu_seconds, 5.0)
+            a2.prewarm_ms = min(args.prewarm_ms, 200.0)
+            a2.reps = min(args.reps, 3)
+            try:
+                o2 = measure(a2, w2, ctx)
+                o2["workload_key"] = w2
+                sec.append(o2)
+            except Exception as e:   # a secondary line never costs the headline
+                sec.append({"workload_key": w2, "error": str(e)[:300]})
+            torch.cuda.empty_cache()
+        out["secondary"] = sec
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

@@ -1155,3 +1155,11 @@ def test_matmul_4bit_inside_a_hip_graph():
             g.replay()
         torch.cuda.synchronize()
         assert torch.equal(y, eager), M
+
+
+def test_synthetic_inputs_generated_on_the_gpu_equal_the_host_form():
+    """bench.py's inputs (synthetic.normal_device on the GPU) are the bits of synthetic.normal on the host, f64 -> 16-bit rounding
+    included."""
+    for dt in (torch.float16, torch.bfloat16, torch.float32):
+        for seed, std, shape in ((1234, 1.0, (513, 1031)), (4321, 0.02, (64, 4096))):
+            assert torch.equal(synthetic.normal(shape, dt, seed=seed, std=std), synthetic.normal_device(shape, dt, seed=seed, std=std, device=DEV).cpu())

@@ -209,3 +209,12 @@ def test_absmax_descriptor_never_hands_the_kernels_a_host_pointer_or_a_short_abs
     with pytest.raises(ValueError, match="absmax has 7 elements, expected 8"):
         _check_absmax_count(torch.zeros(7), 2, 256, 64, "matmul_4bit")
     _check_absmax_count(torch.zeros(8), 2, 256, 64, "matmul_4bit")
+
+
+def test_synthetic_device_form_equals_the_numpy_form():
+    """bench.py draws its inputs with synthetic.normal_device (torch integer ops, runs on the GPU); it must give the bits of
+    synthetic.normal (numpy), which the goldens and the parity tests use."""
+    from mps_bitsandbytes_amd import synthetic
+    for dt in (torch.float16, torch.bfloat16, torch.float32):
+        for seed, std, shape in ((1234, 1.0, (257, 1031)), (4321, 0.02, (5, 70)), (7, 3.5, (100000,))):
+            assert torch.equal(synthetic.normal(shape, dt, seed=seed, std=std), synthetic.normal_device(shape, dt, seed=seed, std=std, device="cpu"))

@@ -89,6 +89,7 @@ if "FETCH_SIZE" in res:
     # HBM traffic of the GEMV (M = 1, 64 rotating layers) and of the int8 GEMM, same counters and correction
     for wl, sub, key, alg in (("nf4_m1", "k_gemv4", "k_gemv4_bytes_per_launch", 9453568),
                               ("int8_4096", "k_gemm_dense", "k_gemm_i8_bytes_per_launch", 2 * 4096 * 4096 + 4096 * 4096 * 2 + 2 * 4096 * 4),   # the int8 form of k_gemm_dense (the transpose pass is a separate kernel)
+                              ("nf4dq_ffn", "k_gemm_dense", "nf4dq_ffn_gemm_dense_bytes_per_launch", (4096 * 4096 + 11008 * 4096 + 4096 * 11008) * 2),
                               # OutlierAwareLinear's GEMM: int8 A and W, 16-bit out, scales, 16 outlier columns (compact activations, weights), bias
                               ("outlier", "k_gemm_dense", "k_gemm_i8_outlier_bytes_per_launch",
                                2 * 4096 * 4096 + 4096 * 4096 * 2 + 2 * 4096 * 4 + 2 * 4096 * 16 * 2 + 4096 * 2)):
@@ -98,5 +99,22 @@ if "FETCH_SIZE" in res:
             out[key] = int((2 * f[0] + w[0]) * 1024)
             out[key.replace("_bytes_per_launch", "_detail")] = {"FETCH_SIZE_KB_raw": f[0], "WRITE_SIZE_KB": w[0], "dispatches": f[1],
                                                                 "algorithmic_bytes_per_launch": alg}
+    # bytes of a whole STEP (every launch of one matmul call): the line's roofline.traffic.  (FETCH_SIZE doubled per launch kind.)
+    def step_bytes(dirtag, subs):
+        tot = 0
+        for sub in subs:
+            f = kernel_counter_mean(f"{dirtag}_fetch", sub, "FETCH_SIZE")
+            w = kernel_counter_mean(f"{dirtag}_write", sub, "WRITE_SIZE")
+            if not (f and w):
+                return None
+            tot += int((2 * f[0] + w[0]) * 1024)
+        return tot
+    for key, dirtag, subs, alg in (("nf4_m4096_step_bytes", tag, ("k_dequantize_4bit", "k_gemm_dense"), 76546048),
+                                   ("nf4dq_ffn_step_bytes", f"{tag}_nf4dq_ffn", ("k_dequantize_4bit", "k_gemm_dense"), 146991872),
+                                   ("int8_4096_step_bytes", f"{tag}_int8_4096", ("k_transpose_i8", "k_gemm_dense"), 67141632)):
+        v = step_bytes(dirtag, subs)
+        if v is not None:
+            out[key] = v
+            out[key + "_algorithmic"] = alg
     json.dump(out, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
     print(json.dumps({k: v for k, v in out.items() if k != "counters"}, indent=1))
