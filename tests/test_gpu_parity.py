@@ -977,6 +977,32 @@ def test_bench_gpus_flag_spawns_ranks_and_gathers_the_unsharded_result():
         assert rec[curve]["value"] > 0
 
 
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: the real RCCL path (one-GPU boxes rehearse it over gloo above)")
+def test_bench_two_ranks_on_the_real_nccl_backend():
+    """`bench.py --gpus 2 --verify` on the real `nccl` (= RCCL) backend, one rank per GPU: init_process_group
+    with device_id, the async all-gather of step i on RCCL's stream under the GEMM of step i+1, ChunkedGather, and the gathered
+    output == the unsharded result.  Skipped on one-GPU boxes."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("BENCH_REHEARSE", None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+                        "--reps", "2", "--prewarm-ms", "0", "--no-cpu-baseline", "--no-gemv", "--no-empirical", "--verify"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    rec = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 2 and rec["verified"] is True
+    assert "RCCL" in rec["config"]["parallelism"]
+    for curve in ("gemm_only", "sync", "overlapped", "chunked"):
+        assert rec[curve]["value"] > 0
+
+
 def test_dequant_absmax_legacy_form_bit_exact():
     """functional.py:866-889, the non-QuantState form, against the reference's outputs (g8_misc.npz) and the oracle."""
     import json
