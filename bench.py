@@ -581,7 +581,7 @@ def measure(args, wl, ctx):
            if two_launch else "one fused dequant + MFMA launch per step")
     out["config"] = {"workload": {"nf4_m4096": f"Linear4bit-style NF4 matmul_4bit, weight 4096x4096 bf16-origin bs64, M=4096 rows per GPU: {how}",
                                   "nf4dq_ffn": f"NF4 + double-quant absmax matmul_4bit, weight 11008x4096 bf16 bs64, M=4096: {how}",
-                                  "int8_4096": "rowwise INT8 matmul_int8 4096x4096x4096 on int8 MFMA (A by row, B [K, N] by column)",
+                                  "int8_4096": "rowwise INT8 matmul_int8 4096x4096x4096 on int8 MFMA (A by row, B [K, N] by column, read in place)",
                                   "nf4_m1": "fused NF4 dequant+GEMV, weight 4096x4096 fp16 bs64, M=1, rotating over 64 layers (one HIP graph of the 64 launches per step)"}[wl],
                      "global_rows": M_global, "rows_per_gpu": M, "N": N, "K": K, "parallelism": par, "kernel": kernel_name}
     out["no_prewarm"] = {"ms_per_step": round(cold[0] / args.steps * 1e3, 5),
@@ -670,9 +670,8 @@ def measure(args, wl, ctx):
             out["roofline"]["dequantize_us"] = round(deq_us, 2)
             del Wd, Yd
         if wl == "int8_4096":
-            out["roofline"]["launches"] = ["k_transpose_i8 (B [K, N] -> [N, K] into the workspace)", "k_gemm_dense<I8>"] if "dense" in kernel_name else [kernel_name]
-            out["roofline"]["dominant_kernel"] = {"kernel": kernel_name, "traffic": traffic.get("k_gemm_i8_bytes_per_launch"),
-                                                  "note": "PMC bytes of the GEMM launch alone"}
+            out["roofline"]["launches"] = (["k_gemm_i8_inplace (four waves, B [K, N] read in place: no transpose pass, no workspace)"] if kernel_name == "i8_inplace4"
+                                           else ["k_transpose_i8 (B [K, N] -> [N, K] into the workspace)", "k_gemm_dense<I8>"] if "dense" in kernel_name else [kernel_name])
 
     if args.verify and do_gather:
         # gathered == unsharded: rank 0 rebuilds every rank's rows and runs the whole batch through the same kernel

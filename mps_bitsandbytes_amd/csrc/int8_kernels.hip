@@ -535,6 +535,8 @@ int matmul_int8_nt_dispatch(const int8_t *A, const int8_t *Bt, const float *sA, 
     return check_launch("matmul_int8(mfma)");
 }
 
+bool gemm_i8_inplace_shape(const int8_t *, const int8_t *, int64_t, int64_t, int64_t);
+int launch_gemm_i8_inplace(const int8_t *, const int8_t *, const float *, const float *, int64_t, int64_t, int64_t, int, void *, hipStream_t);
 // matmul_int8 reads B as the reference passes it, [K, N] row-major.  Large aligned problems go straight to the 256 x 256
 // kernel's transposing-read form (no workspace); everything else is first re-laid out K-contiguous into the caller's
 // workspace (N * K bytes) or, without one, served by the generic kernel.
@@ -549,12 +551,16 @@ bool matmul_int8_direct(const int8_t *A, const int8_t *B, int64_t M, int64_t N, 
            ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0;
 }
 int64_t matmul_int8_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+    if (gemm_i8_inplace_shape(nullptr, nullptr, M, N, K)) return 0;   // four waves, B read in place (gemm_i8_inplace.h)
     if (matmul_int8_dense(M, N, K)) return N * K;     // B^T for the dense pipeline (without it: the in-place kernel below)
     return matmul_int8_direct(nullptr, nullptr, M, N, K) ? 0 : N * K;
 }
 
 int matmul_int8_dispatch(const int8_t *A, const int8_t *B, const float *sA, const float *sB, int64_t M, int64_t N,
                          int64_t K, int out_dtype, void *out, void *workspace, hipStream_t st) {
+    // large aligned problems: the four-wave pipeline with B read in place (round 3: 52 us at 4096^3 against 61 us for the
+    // transpose pass + k_gemm_dense<I8>; no workspace)
+    if (gemm_i8_inplace_shape(A, B, M, N, K)) return launch_gemm_i8_inplace(A, B, sA, sB, M, N, K, out_dtype, out, st);
     if (workspace != nullptr && matmul_int8_dense(M, N, K) &&
         ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(workspace)) & 15) == 0) {
         int8_t *Bt = static_cast<int8_t *>(workspace);

@@ -532,26 +532,23 @@ def test_g5_matmul_int8_and_linear8bit(golden):
                                    (2500, 2624, 384), (2560, 2560, 384), (4096, 4096, 4096)])
 def test_matmul_int8_mfma_exact_vs_integer_reference(shape):
     """BASELINE configs[3] (4096^3) and smaller: the int8 MFMA contraction is exact in int32, so the
-    f32 result must match torch's integer matmul formula to f32 rounding.  N % 16 == 0 and K % 128 == 0 with >= 96 tiles
-    take the workspace-free form (B read as [K, N] through ds_read_b64_tr_b8); (2500, 2600, 384) the transposed one."""
+    f32 result must match torch's integer matmul formula to f32 rounding.  N % 16 == 0 and K % 128 == 0 with >= 96 tiles need
+    no workspace: B is read where it lies ([K, N]) through ds_read_b64_tr_b8 -- from K = 256 up by the four-wave kernel
+    (round 3, gemm_i8_inplace.h; equal bit for bit to the transposed k_gemm_dense<I8> path it replaced:
+    profiles/r03_int8_inplace_ab.txt), at K = 128 by the 8-wave one; (2500, 2600, 384) takes the transposed path."""
     M, N, K = shape
     direct = K % 128 == 0 and N % 16 == 0 and ((M + 255) // 256) * ((N + 255) // 256) >= 96
-    dense = direct and K >= 256 and N % 64 == 0      # with scratch: B transposed once + the four-wave pipeline (gemm_dense.h, I8)
-    assert int(_native.lib().mbnb_matmul_int8_workspace_bytes(M, N, K)) == (0 if direct and not dense else N * K)
+    four = direct and K >= 256
+    assert int(_native.lib().mbnb_matmul_int8_workspace_bytes(M, N, K)) == (0 if direct else N * K)
     A = synthetic.int8_tensor((M, K), seed=80).to(DEV)
     B = synthetic.int8_tensor((K, N), seed=81).to(DEV)
     sa = (synthetic.normal((M,), torch.float32, seed=82).abs() + 0.5).to(DEV)
     sb = (synthetic.normal((N,), torch.float32, seed=83).abs() + 0.5).to(DEV)
     out = bnb.matmul_int8(A, B, sa, sb, torch.float32)
-    assert _native.last_kernel() == ("i8_transpose+dense" if dense else "i8_mfma256" if M >= 2500 else "i8_mfma128")
-    if dense:   # the in-place kernel (no scratch) computes the same int32 sums and the same f32 products
-        bnb.functional.DECODE_ONCE = False
-        try:
-            out2 = bnb.matmul_int8(A, B, sa, sb, torch.float32)
-            assert _native.last_kernel() == "i8_mfma256"
-        finally:
-            bnb.functional.DECODE_ONCE = True
-        assert torch.equal(out, out2)
+    assert _native.last_kernel() == ("i8_inplace4" if four else "i8_mfma256" if (direct or M >= 2500) else "i8_mfma128")
+    if four:    # run-to-run determinism, and the 16-bit epilogue against the f32 one (one more rounding)
+        assert torch.equal(out, bnb.matmul_int8(A, B, sa, sb, torch.float32))
+        assert torch.equal(bnb.matmul_int8(A, B, sa, sb, torch.bfloat16), out.to(torch.bfloat16))
     rows = torch.arange(0, M, max(1, M // 64), device=DEV)
     exact = (A[rows].double() @ B.double())  # exact: |sum| < 2^53
     ref = exact * (sa[rows].double() / 127.0).unsqueeze(1) * (sb.double() / 127.0).unsqueeze(0)
@@ -1189,3 +1186,34 @@ def test_synthetic_inputs_generated_on_the_gpu_equal_the_host_form():
     for dt in (torch.float16, torch.bfloat16, torch.float32):
         for seed, std, shape in ((1234, 1.0, (513, 1031)), (4321, 0.02, (64, 4096))):
             assert torch.equal(synthetic.normal(shape, dt, seed=seed, std=std), synthetic.normal_device(shape, dt, seed=seed, std=std, device=DEV).cpu())
+
+
+@pytest.mark.parametrize("M,N,K,dt,qt,dq,with_bias", [(2048, 3072, 256, torch.bfloat16, "nf4", False, False),
+                                                       (2500, 2600, 512, torch.float16, "fp4", False, True),
+                                                       (2304, 3000, 768, torch.bfloat16, "nf4", True, True),
+                                                       (4096, 4096, 1024, torch.float16, "nf4", True, False)])
+def test_matmul_fused4_flag_equals_the_decode_once_path(M, N, K, dt, qt, dq, with_bias):
+    """k_gemm_fused4 (round 3; csrc/gemm_fused4.h: the 4-bit decode inside the four-wave MFMA pipeline, one launch, no scratch),
+    reached through MBNB_MATMUL_FUSED4 of mbnb_matmul_4bit_ex: same B-operand bits and MFMA order as dequantize_4bit +
+    k_gemm_dense, hence the same output bits; plain and double-quantised absmax, both tables, ragged M / N, bias; and the oracle."""
+    import ctypes
+    lib = _native.lib()
+    W = synthetic.normal((N, K), dt, seed=401, std=0.05 if dq else 1.0)
+    x = synthetic.normal((M, K), dt, seed=402).to(DEV)
+    bias = synthetic.normal((N,), dt, seed=403).to(DEV) if with_bias else None
+    packed, st = bnb.quantize_4bit(W.to(DEV), blocksize=64, quant_type=qt, compress_statistics=dq)
+    y_ref = bnb.matmul_4bit(x, packed, st, bias)
+    assert _native.last_kernel().startswith("dequant+dense")
+    keep = []
+    desc = bnb.functional._absmax_desc(st.absmax, st.state2, keep)
+    out = torch.full((M, N), float("nan"), dtype=dt, device=DEV)
+    code = _native.DTYPE_CODE[dt]
+    rc = lib.mbnb_matmul_4bit_ex(x.data_ptr(), M, K, packed.data_ptr(), ctypes.byref(desc), N, K, 64, _native.QUANT_CODE[qt], code,
+                                 None if bias is None else bias.data_ptr(), code, out.data_ptr(), None, 0, 2, _native.stream_ptr(DEV))
+    assert rc == 0, lib.mbnb_last_error()
+    assert _native.last_kernel() == "fused4"
+    assert torch.equal(out, y_ref)
+    rows = torch.arange(0, M, max(1, M // 32))[:32]
+    op, oa, os2 = oracle.quantize_4bit(W, 64, qt, dq)
+    ref = oracle.matmul_4bit(x.cpu()[rows], op, oa, (N, K), 64, qt, dt, None if bias is None else bias.cpu(), None, os2)
+    assert rel_fro(out.cpu()[rows], ref) <= TOL[dt]

@@ -88,7 +88,7 @@ if "FETCH_SIZE" in res:
     out["counters"] = res
     # HBM traffic of the GEMV (M = 1, 64 rotating layers) and of the int8 GEMM, same counters and correction
     for wl, sub, key, alg in (("nf4_m1", "k_gemv4", "k_gemv4_bytes_per_launch", 9453568),
-                              ("int8_4096", "k_gemm_dense", "k_gemm_i8_bytes_per_launch", 2 * 4096 * 4096 + 4096 * 4096 * 2 + 2 * 4096 * 4),   # the int8 form of k_gemm_dense (the transpose pass is a separate kernel)
+                              ("int8_4096", "k_gemm_i8_inplace", "k_gemm_i8_bytes_per_launch", 2 * 4096 * 4096 + 4096 * 4096 * 2 + 2 * 4096 * 4),   # matmul_int8's single launch (round 3: B read in place)
                               ("nf4dq_ffn", "k_gemm_dense", "nf4dq_ffn_gemm_dense_bytes_per_launch", (4096 * 4096 + 11008 * 4096 + 4096 * 11008) * 2),
                               # OutlierAwareLinear's GEMM: int8 A and W, 16-bit out, scales, 16 outlier columns (compact activations, weights), bias
                               ("outlier", "k_gemm_dense", "k_gemm_i8_outlier_bytes_per_launch",
@@ -111,7 +111,7 @@ if "FETCH_SIZE" in res:
         return tot
     for key, dirtag, subs, alg in (("nf4_m4096_step_bytes", tag, ("k_dequantize_4bit", "k_gemm_dense"), 76546048),
                                    ("nf4dq_ffn_step_bytes", f"{tag}_nf4dq_ffn", ("k_dequantize_4bit", "k_gemm_dense"), 146991872),
-                                   ("int8_4096_step_bytes", f"{tag}_int8_4096", ("k_transpose_i8", "k_gemm_dense"), 67141632)):
+                                   ("int8_4096_step_bytes", f"{tag}_int8_4096", ("k_gemm_i8_inplace",), 67141632)):
         v = step_bytes(dirtag, subs)
         if v is not None:
             out[key] = v
