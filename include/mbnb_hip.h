@@ -209,6 +209,21 @@ int mbnb_matmul_4bit_ex(const void *A, int64_t M, int64_t K, const uint8_t *pack
                         int quant_type, int w_dtype, const void *bias, int out_dtype, void *out,
                         void *workspace, int64_t workspace_bytes, int flags, void *stream);
 
+/* mbnb_matmul_4bit_ex with a SYNC area: where mbnb_matmul_4bit_sync_bytes(...) > 0 (blocksize 64, plain f32 absmax, 3840 < M
+ * <= 4096 rows, K % 512 == 0, K_weight == K, at most one 256 x 256 tile per compute unit of the device) and the workspace holds
+ * the N x K x 2-byte scratch, the weight is decoded ONCE INSIDE the GEMM launch (csrc/gemm_dq.h: one launch instead of
+ * dequantize_4bit + dense GEMM; same bits).  `sync`: mbnb_matmul_4bit_sync_bytes bytes of device memory that are ZERO on entry;
+ * the launch leaves them zero, so one buffer per (device, stream) serves every call -- it must not be shared by launches that
+ * can run concurrently.  Word [tiles_n * 66] of it is an error word: non-zero after a launch = a hand-off timed out (some
+ * workgroup was not resident for seconds) and that call's output is not valid.  sync == NULL, or a shape the path does not
+ * serve: exactly mbnb_matmul_4bit_ex. */
+int64_t mbnb_matmul_4bit_sync_bytes(int64_t M, int64_t N, int64_t K, int64_t K_weight, int blocksize);
+int mbnb_matmul_4bit_sync(const void *A, int64_t M, int64_t K, const uint8_t *packed,
+                          const mbnb_absmax *absmax, int64_t N, int64_t K_weight, int blocksize,
+                          int quant_type, int w_dtype, const void *bias, int out_dtype, void *out,
+                          void *workspace, int64_t workspace_bytes, int flags, void *sync, int64_t sync_bytes,
+                          void *stream);
+
 /* The dense half of the large-M path on its own: out[M, N] = A[M, K] * W[N, ldw]^T (+ bias) for an f16 / bf16 weight that is
  * already in the compute dtype (rows ldw >= K elements apart) -- the F.linear of functional.py:767 on the tensor
  * functional.py:756 produced.  mbnb_matmul_4bit_ws calls it internally; exported for callers that keep a dequantised weight

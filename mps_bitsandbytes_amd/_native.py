@@ -52,6 +52,9 @@ _SIGNATURES = {
                                   c_int, c_int, c_void_p]),
     "mbnb_matmul_4bit": (c_int, [c_void_p, c_int64, c_int64, c_void_p, POINTER(AbsmaxDesc), c_int64, c_int64,
                                  c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "mbnb_matmul_4bit_sync_bytes": (c_int64, [c_int64, c_int64, c_int64, c_int64, c_int]),
+    "mbnb_matmul_4bit_sync": (c_int, [c_void_p, c_int64, c_int64, c_void_p, POINTER(AbsmaxDesc), c_int64, c_int64, c_int, c_int, c_int,
+                                      c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p]),
     "mbnb_matmul_4bit_workspace_bytes": (c_int64, [c_int64, c_int64, c_int64]),
     "mbnb_matmul_4bit_workspace_bytes_kw": (c_int64, [c_int64, c_int64, c_int64, c_int64]),
     "mbnb_matmul_4bit_workspace_bytes_dt": (c_int64, [c_int64, c_int64, c_int64, c_int64, c_int]),

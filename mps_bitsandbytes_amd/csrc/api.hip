@@ -74,6 +74,9 @@ int64_t gemm_mid_workspace_bytes(int64_t, int64_t, int64_t);
 int64_t gemm_small_workspace_bytes(int64_t, int64_t, int64_t, int64_t);
 int64_t gemm_f32_workspace_bytes(int64_t, int64_t, int64_t, int64_t);
 int64_t gemm_dense_workspace_bytes(int64_t, int64_t, int64_t, int64_t);
+int64_t gemm_dq_sync_bytes(int64_t, int64_t, int64_t, int64_t, int);
+int matmul_4bit_dq_path(const void *, int64_t, int64_t, const uint8_t *, const AbsmaxView &, int64_t, int64_t, int, int, int, const void *, int, void *,
+                        void *, int64_t, void *, int64_t, hipStream_t);
 bool gemm_dense_shape(int64_t, int64_t, int64_t, int64_t);
 int64_t gemm_dense_slices(int64_t, int64_t, int64_t);
 int gemm_dense_direct(const void *, const void *, int, const void *, int, void *, int64_t, int64_t, int64_t, int64_t, float *, int64_t, int,
@@ -246,6 +249,27 @@ int mbnb_matmul_4bit_ex(const void *A, int64_t M, int64_t K, const uint8_t *pack
     // the split-K workspace travels down the dispatch as an argument (no per-call state is kept anywhere)
     return matmul_4bit_dispatch(A, M, K, packed, v, N, K_weight, blocksize, quant_type, w_dtype, bias, out_dtype, out,
                                 workspace, workspace ? workspace_bytes : 0, flags, static_cast<hipStream_t>(stream));
+}
+
+int64_t mbnb_matmul_4bit_sync_bytes(int64_t M, int64_t N, int64_t K, int64_t K_weight, int blocksize) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    return gemm_dq_sync_bytes(M, N, K, K_weight, blocksize);
+}
+
+int mbnb_matmul_4bit_sync(const void *A, int64_t M, int64_t K, const uint8_t *packed, const mbnb_absmax *absmax, int64_t N,
+                          int64_t K_weight, int blocksize, int quant_type, int w_dtype, const void *bias, int out_dtype,
+                          void *out, void *workspace, int64_t workspace_bytes, int flags, void *sync, int64_t sync_bytes, void *stream) {
+    if (sync != nullptr && workspace != nullptr && !(flags & (MBNB_MATMUL_FUSED_ONLY | MBNB_MATMUL_FUSED4)) && dtype_ok(w_dtype) &&
+        dtype_ok(out_dtype) && qt_ok(quant_type) && absmax != nullptr && A && packed && out && M > 0 && N > 0 && K > 0 &&
+        pow2(blocksize) && K_weight >= K) {
+        AbsmaxView v;
+        if (int rc = absmax_view(absmax, "matmul_4bit", v)) return rc;
+        const int rc = matmul_4bit_dq_path(A, M, K, packed, v, N, K_weight, blocksize, quant_type, w_dtype, bias, out_dtype, out, workspace,
+                                           workspace_bytes, sync, sync_bytes, static_cast<hipStream_t>(stream));
+        if (rc != MBNB_NOT_APPLICABLE) return rc;
+    }
+    return mbnb_matmul_4bit_ex(A, M, K, packed, absmax, N, K_weight, blocksize, quant_type, w_dtype, bias, out_dtype, out, workspace,
+                               workspace_bytes, flags, stream);
 }
 
 int mbnb_matmul_4bit_ws(const void *A, int64_t M, int64_t K, const uint8_t *packed, const mbnb_absmax *absmax, int64_t N,

@@ -68,6 +68,37 @@ _warned: set = set()
 # linear_int8 and matmul_fp8_e4m3 alike (the FUSED_ONLY flag travels to all three entry points).  The scratch is transient:
 # N x K_weight x 2 bytes per call from torch's caching allocator (32 MB for a 4096^2 layer, ~1 GB for a 128k x 4096 head).
 DECODE_ONCE = True
+# Large M (3840 < M <= 4096 rows, blocksize 64, plain absmax, one tile per compute unit): decode the weight once INSIDE the GEMM
+# launch instead of in a launch of its own (csrc/gemm_dq.h; same bits).  OFF by default: at 4096^3 the one-launch form measures
+# 106-107 us against 105 us for the two launches (profiles/r03_dq_ablation.txt: the hand-off's write-through stores, agent-scope
+# atomics and the 3.6 us start-up eat what the hidden dequantise pass saves), and it needs every workgroup resident at once.
+DECODE_IN_LAUNCH = False
+_SYNC_AREAS: dict = {}
+
+
+def _sync_area(device, M, N, K, K_weight, blocksize):
+    """The zeroed hand-off area of the in-launch decode path for this (device, stream), or None where the path does not apply.
+    The kernel leaves it zeroed, so it is allocated and cleared once."""
+    need = int(_native.lib().mbnb_matmul_4bit_sync_bytes(M, N, K, K_weight, int(blocksize)))
+    if need <= 0:
+        return None
+    key = (device.index if device.index is not None else torch.cuda.current_device(), int(torch.cuda.current_stream(device).cuda_stream))
+    buf = _SYNC_AREAS.get(key)
+    if buf is None or buf.numel() < need:
+        buf = torch.zeros(max(need, 32768), dtype=torch.uint8, device=device)
+        _SYNC_AREAS[key] = buf
+    return buf
+
+
+def in_launch_errors() -> int:
+    """Non-zero words of the in-launch path's sync areas (synchronises): 0 = every hand-off of every call so far went through and
+    every flag is back to zero.  A timed-out hand-off (a workgroup not resident for seconds) leaves its error word set."""
+    bad = 0
+    for buf in _SYNC_AREAS.values():
+        bad += int((buf != 0).sum().item())
+    return bad
+
+
 MATMUL_FUSED_ONLY = 1   # include/mbnb_hip.h MBNB_MATMUL_FUSED_ONLY: the flags word of mbnb_matmul_4bit_ex / mbnb_linear_int8_ex / mbnb_linear_fp8_ex
 
 
@@ -566,11 +597,21 @@ def matmul_4bit(
     else:
         ws_bytes = int(_native.lib().mbnb_matmul_4bit_splitk_workspace_bytes(M, N, K))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=A.device) if ws_bytes > 0 else None
+    flags = 0 if DECODE_ONCE else MATMUL_FUSED_ONLY
+    # Where the shape allows it the weight is decoded once INSIDE the GEMM launch (csrc/gemm_dq.h): the launch needs a small
+    # sync area that is zero on entry and that it leaves zero -- one persistent buffer per (device, stream), made on first use.
+    sync = _sync_area(A.device, M, N, K, K_weight, blocksize) if (DECODE_ONCE and DECODE_IN_LAUNCH and ws is not None and quant_state.state2 is None) else None
     with torch.cuda.device(A.device):
-        check(_native.lib().mbnb_matmul_4bit_ex(
-            ptr(A2), M, K, ptr(packed), ctypes.byref(desc), N, K_weight, int(blocksize),
-            _native.QUANT_CODE[quant_state.quant_type], w_code, ptr(bias_w), _native.DTYPE_CODE[out_dtype],
-            ptr(out), ptr(ws), ws_bytes, 0 if DECODE_ONCE else MATMUL_FUSED_ONLY, stream_ptr(A.device)), "matmul_4bit")
+        if sync is not None:
+            check(_native.lib().mbnb_matmul_4bit_sync(
+                ptr(A2), M, K, ptr(packed), ctypes.byref(desc), N, K_weight, int(blocksize),
+                _native.QUANT_CODE[quant_state.quant_type], w_code, ptr(bias_w), _native.DTYPE_CODE[out_dtype],
+                ptr(out), ptr(ws), ws_bytes, flags, ptr(sync), sync.numel(), stream_ptr(A.device)), "matmul_4bit")
+        else:
+            check(_native.lib().mbnb_matmul_4bit_ex(
+                ptr(A2), M, K, ptr(packed), ctypes.byref(desc), N, K_weight, int(blocksize),
+                _native.QUANT_CODE[quant_state.quant_type], w_code, ptr(bias_w), _native.DTYPE_CODE[out_dtype],
+                ptr(out), ptr(ws), ws_bytes, flags, stream_ptr(A.device)), "matmul_4bit")
     if out_dtype != compute_dtype:
         out = out.to(compute_dtype)
     return out.reshape(*orig_shape[:-1], N)

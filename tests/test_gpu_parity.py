@@ -1217,3 +1217,24 @@ def test_matmul_fused4_flag_equals_the_decode_once_path(M, N, K, dt, qt, dq, wit
     op, oa, os2 = oracle.quantize_4bit(W, 64, qt, dq)
     ref = oracle.matmul_4bit(x.cpu()[rows], op, oa, (N, K), 64, qt, dt, None if bias is None else bias.cpu(), None, os2)
     assert rel_fro(out.cpu()[rows], ref) <= TOL[dt]
+
+
+@pytest.mark.parametrize("M,N,K,dt,qt,with_bias", [(4096, 4096, 4096, torch.bfloat16, "nf4", False), (4000, 2560, 2048, torch.float16, "fp4", True),
+                                                   (3900, 1000, 2048, torch.bfloat16, "nf4", True)])
+def test_matmul_in_launch_decode_equals_the_two_launch_path(M, N, K, dt, qt, with_bias, monkeypatch):
+    """k_gemm_dq (round 3, csrc/gemm_dq.h; functional.DECODE_IN_LAUNCH, off by default): the weight decoded once INSIDE the GEMM
+    launch by the launch's own workgroups, handed between them through agent-scope flags.  Same Wd bits and the same pipeline as
+    dequantize_4bit + k_gemm_dense -> the same output bits; repeated calls (the flags must come back to zero each time); no
+    hand-off may time out."""
+    W = synthetic.normal((N, K), dt, seed=411)
+    x = synthetic.normal((M, K), dt, seed=412).to(DEV)
+    bias = synthetic.normal((N,), dt, seed=413).to(DEV) if with_bias else None
+    packed, st = bnb.quantize_4bit(W.to(DEV), blocksize=64, quant_type=qt)
+    y_ref = bnb.matmul_4bit(x, packed, st, bias)
+    assert _native.last_kernel().startswith("dequant+dense")
+    monkeypatch.setattr(bnb.functional, "DECODE_IN_LAUNCH", True)
+    for _ in range(3):
+        y = bnb.matmul_4bit(x, packed, st, bias)
+        assert _native.last_kernel() == "dq_inlaunch"
+        assert torch.equal(y, y_ref)
+    assert bnb.functional.in_launch_errors() == 0
