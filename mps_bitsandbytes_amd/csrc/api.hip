@@ -328,7 +328,8 @@ int mbnb_gemm_dense(const void *A, const void *W, int dtype, const void *bias, i
     // slices: bits 0-7 the K slices; bits 8-15 the row extent of a tile, 0 (library's choice), 128 or 256, in units of 128 rows
     const int tile_m = ((slices >> 8) & 0xFF) * 128;
     slices &= 0xFF;
-    if (tile_m != 0 && tile_m != 128 && tile_m != 256) return fail(MBNB_ERR_ARG, "gemm_dense: tile rows must be 128 or 256");
+    if (tile_m != 0 && tile_m != 128 && tile_m != 256 && tile_m != 384) return fail(MBNB_ERR_ARG, "gemm_dense: tile code must be 0, 1, 2 or 3");
+    if (tile_m == 384 && (K < 192 || (slices & 0xFF) > 1)) return fail(MBNB_ERR_ARG, "gemm_dense: the 128 x 128 tile needs K >= 192 and takes no K slices");
     if ((dtype != MBNB_F16 && dtype != MBNB_BF16) || !dtype_ok(out_dtype)) return fail(MBNB_ERR_ARG, "gemm_dense: bad dtype");
     if (M <= 0 || N <= 0 || K < 128 || K % 64 || ldw < K || ldw % 8) return fail(MBNB_ERR_SHAPE, "gemm_dense: bad shape");
     if (256 * ldw * 2 >= ((int64_t)1 << 31)) return fail(MBNB_ERR_SHAPE, "gemm_dense: K too large");

@@ -6,6 +6,7 @@
 //   [0, wd_bytes)                    Wd [N, K_weight] in the compute dtype, wd_bytes = N * K_weight * 2 rounded up to 256
 //   [wd_bytes, + slices * M * N * 4) f32 partials of the split-K slices (none when slices == 1)
 #include "gemm_dense.h"
+#include "gemm_dense128.h"
 #include "gemm_mid.h"
 
 namespace mbnb {
@@ -21,12 +22,24 @@ int dequantize_4bit_dispatch(const uint8_t *, const AbsmaxView &, int64_t, int64
 // has the same bits for a row whatever M it is computed in (the tile shape does not change a row's summation order, the
 // slice count does), which is what lets row shards and row chunks of a large batch (sharding.py, bench.py --gpus N
 // --verify) be compared bit for bit with the unsharded result.
+// Round 3: a third tile shape, 128 x 128 on three LDS stages (fm = 2, gemm_dense128.h; never split): 0.47 us per k-step with every
+// CU busy, 0.36 us at <= 128 tiles (tools/exp/ab_dense128.py, profiles/r03_dense128_ab.txt).  It replaces the split plans wherever
+// its tiles fit the chip in one round: 1024 x 4096 x 4096 35.9 us against 45.9 (256 x 128 tiles x 2 slices + the reduction pass),
+// 512 x 4096^2 28.3 against 34.1, 768 x 4096^2 31.0 against 40.0, 1000 x 2600 x 1024 10.3 against 15.5; two rounds of it lose to one
+// round of 256 x 128 tiles (1536 x 4096^2: 59.6 against 52.5).  A split plan is charged 6 us for its second launch.  Results equal
+// the unsplit 256-wide tiles' bit for bit (same summation order per row).
 struct DensePlan { int fm; int64_t slices; };
 DensePlan gemm_dense_plan(int64_t M, int64_t N, int64_t K) {
     const int64_t tn = (N + 255) / 256, tiles8 = ((M + 255) / 256) * tn, tiles4 = ((M + 127) / 128) * tn;
+    const int64_t tiles2 = ((M + 127) / 128) * ((N + 127) / 128);
     const int64_t steps = K / 64;
     DensePlan best{8, 1};
     double best_t = 1e30;
+    if (K >= 192 && tiles8 < 96) {     // from 96 tiles of 256 x 256 up the big tiles stay (and nothing is ever split there)
+        const int64_t rounds = (tiles2 + 255) / 256;
+        best_t = (double)rounds * (double)steps * (tiles2 <= 128 ? 0.36 : 0.47);
+        best = DensePlan{2, 1};
+    }
     for (int fm = 8; fm >= 4; fm -= 4) {
         const int64_t tiles = fm == 8 ? tiles8 : tiles4;
         const double step = fm == 8 ? 1.3 : 0.75;
@@ -34,7 +47,7 @@ DensePlan gemm_dense_plan(int64_t M, int64_t N, int64_t K) {
             const int64_t per = (steps + s - 1) / s;
             if (s > 1 && (per < 8 || tiles8 >= 96)) break;
             const int64_t rounds = (tiles * s + 255) / 256;
-            const double t = (double)rounds * (double)per * step + (s > 1 ? 8.0 * (double)s * (double)M * (double)N / 6.0e6 : 0.0);
+            const double t = (double)rounds * (double)per * step + (s > 1 ? 6.0 + 8.0 * (double)s * (double)M * (double)N / 6.0e6 : 0.0);
             if (t < best_t * (fm == 8 ? 1.0 : 0.97)) {   // the smaller tile has to win by a margin
                 best_t = t;
                 best = DensePlan{fm, s};
@@ -92,10 +105,22 @@ static int launch_gemm_dense_fm(const T *x, const T *wd, const T *bias, void *ou
     return check_launch("matmul_4bit(dense split-K reduce)");
 }
 
-// fm: 8 / 4 as planned by gemm_dense_plan, 0 = plan here (slices then comes from the caller's workspace check)
+// 128 x 128 tiles (gemm_dense128.h), never split
+template <typename T>
+static int launch_gemm_dense128(const T *x, const T *wd, const T *bias, void *out, int out_dtype, int64_t M, int64_t N, int64_t K,
+                                int64_t ldw, hipStream_t st) {
+    const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
+    auto kern = k_gemm_dense128<T>;
+    if (int rc = ensure_dyn_lds(reinterpret_cast<const void *>(kern), G128_LDS, "matmul_4bit(dense128)")) return rc;
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), G128_LDS, st, x, wd, bias, out, out_dtype, M, N, K, ldw);
+    return check_launch("matmul_4bit(dense128)");
+}
+
+// fm: 8 / 4 as planned by gemm_dense_plan, 2 = 128 x 128 tiles, 0 = plan here (slices then comes from the caller's workspace check)
 template <typename T>
 static int launch_gemm_dense(const T *x, const T *wd, const T *bias, void *out, int out_dtype, int64_t M, int64_t N, int64_t K,
                              int64_t ldw, float *partial, int64_t slices, int fm, hipStream_t st) {
+    if (fm == 2) return launch_gemm_dense128<T>(x, wd, bias, out, out_dtype, M, N, K, ldw, st);
     if (fm == 4) return launch_gemm_dense_fm<T, 4>(x, wd, bias, out, out_dtype, M, N, K, ldw, partial, slices, st);
     return launch_gemm_dense_fm<T, 8>(x, wd, bias, out, out_dtype, M, N, K, ldw, partial, slices, st);
 }
@@ -192,7 +217,7 @@ int launch_gemm_i8_dense(const int8_t *A, const int8_t *Bt, const float *sA, con
 // diagnostic entry for tools/exp (the dense kernel alone on a caller-made Wd)
 int gemm_dense_direct(const void *A, const void *Wd, int dtype, const void *bias, int out_dtype, void *out, int64_t M, int64_t N,
                       int64_t K, int64_t ldw, float *partial, int64_t slices, int tile_m, hipStream_t st) {
-    const int fm = tile_m == 128 ? 4 : (tile_m == 256 ? 8 : gemm_dense_plan(M, N, K).fm);
+    const int fm = tile_m == 128 ? 4 : (tile_m == 256 ? 8 : (tile_m == 384 ? 2 : gemm_dense_plan(M, N, K).fm));   // 384: the code of the 128 x 128 tile
     if (dtype == MBNB_F16)
         return launch_gemm_dense<f16_t>(static_cast<const f16_t *>(A), static_cast<const f16_t *>(Wd), static_cast<const f16_t *>(bias), out,
                                         out_dtype, M, N, K, ldw, partial, slices, fm, st);

@@ -253,6 +253,7 @@ def test_matmul_mfma256_path(case, monkeypatch):
     dict(M=700, N=3800, K=1088, dt=torch.bfloat16, cd=torch.float32),    # split-K with a short last slice, f32 output
     dict(M=384, N=4096, K=4096, dt=torch.bfloat16),                      # 256 x 128 tiles, 48 of them: split-K
     dict(M=257, N=11008, K=512, dt=torch.float16, cs=True),              # 256 x 128 tiles, ragged M (one row in the third tile)
+    dict(M=512, N=2048, K=8192, dt=torch.bfloat16),                      # few tiles, long K: the plan still splits K (round 3)
 ])
 def test_matmul_decode_once_path(case, monkeypatch):
     """Large M through the Python API: dequantize_4bit into the scratch + k_gemm_dense (gemm_dense.h), any blocksize / code
@@ -397,11 +398,13 @@ def test_matmul_row_independence_and_linearity_full_size():
     Yh = bnb.matmul_4bit(X * 0.5, packed, st)
     big = Y.abs() > 1e-2
     assert torch.equal((Yh * 2)[big], Y[big])
-    # the same rows through the other kernels: GEMV (1 row), skinny MFMA (4, 24 rows), k_gemm_small (150, 240), decode once + split-K (500)
-    for rows_n, kern in ((1, "gemv"), (4, "skinny_mfma16"), (24, "skinny_mfma16"), (150, "mfma_small_splitk"), (240, "mfma_small_splitk"), (500, "dequant+dense_splitk")):
+    # the same rows through the other kernels: GEMV (1 row), skinny MFMA (4, 24 rows), k_gemm_small (150, 240), decode once on 128 x 128 tiles (500)
+    for rows_n, kern in ((1, "gemv"), (4, "skinny_mfma16"), (24, "skinny_mfma16"), (150, "mfma_small_splitk"), (240, "mfma_small_splitk"), (500, "dequant+dense")):
         yg = bnb.matmul_4bit(X[:rows_n], packed, st)
         assert _native.last_kernel() == kern
         assert rel_fro(yg, Y[:rows_n]) <= TOL[torch.float16]
+        if rows_n == 500:   # 128 x 128 tiles, unsplit (round 3): a row's summation order is that of the 256 x 256 tiles -> the same bits
+            assert torch.equal(yg, Y[:rows_n])
 
 
 def test_matmul_config_b_double_quant_full_size():
@@ -573,7 +576,8 @@ def test_linear_int8_vs_oracle(shape, dt):
 
 @pytest.mark.parametrize("M,N,K,dt,kern", [(2500, 2600, 192, torch.float16, "w8a16_dequant+dense"),
                                             (4096, 4096, 1024, torch.bfloat16, "w8a16_dequant+dense"),
-                                            (1024, 4096, 2048, torch.bfloat16, "w8a16_dequant+dense_splitk")])
+                                            (1024, 4096, 2048, torch.bfloat16, "w8a16_dequant+dense"),       # 128 x 128 tiles (round 3)
+                                            (512, 2048, 8192, torch.bfloat16, "w8a16_dequant+dense_splitk")])   # few tiles, long K: still split
 def test_linear_int8_decode_once_path(M, N, K, dt, kern, monkeypatch):
     """Linear8bit.forward at large M: dequantize_rowwise into the workspace + k_gemm_dense; parity vs the oracle and equality
     with the fused W8A16 256 x 256 kernel (same B-operand bits) where that one serves the shape."""
@@ -658,6 +662,36 @@ def test_gemm_dense_c_entry_point(M, N, K, ldw, slices, tile, odt, dt):
     assert torch.isfinite(y).all()
     assert rel_fro(y, ref.cpu()) <= TOL[dt]
     assert torch.equal(y, run(128)) and torch.equal(y, run(256)), "tile shape changed the result"
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K,ldw,odt", [(1024, 4096, 1024, 1024, None), (515, 1000, 640, 704, torch.float32), (129, 257, 192, 200, torch.float16),
+                                           (1000, 2600, 1024, 1024, None)])
+def test_gemm_dense_128_tile_equals_the_256_tile(M, N, K, ldw, odt, dt):
+    """k_gemm_dense128 (round 3: 128 x 128 tiles on three LDS stages, what the plan picks where the 256-wide tiles would leave CUs
+    idle or split K) through mbnb_gemm_dense's tile code 3: bit-equal to the unsplit 256 x 256 tiles (same summation order per row),
+    ragged M / N, a weight pitch > K, bias, output casts; and against a float64 product."""
+    lib = _native.lib()
+    odt = odt or dt
+    X = synthetic.normal((M, K), dt, seed=311).to(DEV)
+    Wfull = synthetic.normal((N, ldw), dt, seed=312, std=0.05).to(DEV)
+    b = synthetic.normal((N,), dt, seed=313).to(DEV)
+    code, ocode, sp = _native.DTYPE_CODE[dt], _native.DTYPE_CODE[odt], _native.stream_ptr(DEV)
+
+    def run(tile_code, bias):
+        out = torch.full((M, N), float("nan"), dtype=odt, device=DEV)
+        rc = lib.mbnb_gemm_dense(X.data_ptr(), Wfull.data_ptr(), code, None if bias is None else bias.data_ptr(), ocode, out.data_ptr(), M, N, K, ldw,
+                                 None, 0, 1 | (tile_code << 8), sp)
+        assert rc == 0, (rc, lib.mbnb_last_error())
+        return out
+
+    for bias in (None, b):
+        y128, y256 = run(3, bias), run(2, bias)
+        assert torch.isfinite(y128).all()
+        assert torch.equal(y128, y256)
+    ref = (X.double() @ Wfull[:, :K].double().t() + b.double())
+    ref = ref.to(dt).to(odt) if odt != torch.float32 else ref.to(dt).float()
+    assert rel_fro(run(3, b), ref.cpu()) <= TOL[dt]
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16, torch.float32])
@@ -836,7 +870,7 @@ def test_matmul_4bit_randomized_sweep_round2_kernels():
         cd = None if rng.random() < 0.7 else [torch.float16, torch.bfloat16, torch.float32][int(rng.integers(0, 3))]
         kern = _oracle_vs_gpu_matmul(M, N, K, dt, qt=qt, bs=bs, cs=cs, bias=bias, cd=cd, seed=5000 + case)
         seen[kern] = seen.get(kern, 0) + 1
-    assert {"mfma_small_splitk", "dequant+dense", "dequant+dense_splitk"} <= set(seen), seen
+    assert {"mfma_small_splitk", "dequant+dense"} <= set(seen), seen     # (split-K of the dense path: test_matmul_decode_once_path, test_gemm_dense_c_entry_point)
 
 
 def test_linear_int8_randomized_dispatch_sweep():
