@@ -542,11 +542,13 @@ def matmul_4bit(
     """
     Matrix multiplication with 4-bit quantized weights: ``A[..., K] @ dequant(B)[N, K]^T + bias``.
 
-    Signature of the reference (functional.py:680-773).  One fused HIP kernel for every M (the
-    reference fuses only on MPS and only for M <= 512): the decoded weight is rounded to
-    ``quant_state.dtype`` exactly as ``dequantize_4bit`` would, the contraction runs in that
-    dtype with f32 accumulation, and the result is cast to ``compute_dtype`` (default
-    ``A.dtype``) — the numerics of the reference's CPU branch (functional.py:756-773).
+    Signature of the reference (functional.py:680-773).  Below 256 rows (1.5 M outputs) ONE fused HIP kernel decodes the
+    packed weight inside the GEMV / MFMA GEMM (the reference fuses only on MPS and only for M <= 512); from there up the
+    library does the reference's own two steps (functional.py:753-767) on a transient scratch: ``dequantize_4bit`` once, then
+    a dense MFMA GEMM (``DECODE_ONCE = False`` keeps the fused kernels at every M).  Either way the decoded weight is
+    rounded to ``quant_state.dtype`` exactly as ``dequantize_4bit`` would, the contraction runs in that dtype with f32
+    accumulation, and the result is cast to ``compute_dtype`` (default ``A.dtype``) -- the numerics of the reference's CPU
+    branch (functional.py:756-773).
     """
     if compute_dtype is None:
         compute_dtype = A.dtype
