@@ -98,15 +98,21 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, 
         const int64_t q = nwg / 8, r = nwg % 8, xcd = bid % 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
     }
+    // Round 3: tile columns that do not fill a patch (N = 11008: 43 columns) no longer switch the whole grid to the column-major
+    // order -- there every XCD walks all of A once per round of workgroups (PMC: 1.04 GB of fabric traffic per launch at
+    // 4096 x 11008 x 4096 against 0.21 GB algorithmic, profiles/traffic.json r03); the leading floor(tiles_n / PN) * PN columns keep
+    // their PM x PN patches, only the remainder is walked column by column.
     int64_t tm, tn;
-    if ((tiles_m % PM == 0) && (tiles_n % PN == 0)) {
+    const int64_t full_n = (tiles_m % PM == 0) ? (tiles_n / PN) * PN : 0;
+    if (bid < tiles_m * full_n) {
         const int64_t patch = bid >> 5, within = bid & 31;
         const int64_t patches_m = tiles_m / PM;
         tm = (patch % patches_m) * PM + (within % PM);
         tn = (patch / patches_m) * PN + (within / PM);
     } else {
-        tm = bid % tiles_m;
-        tn = bid / tiles_m;
+        const int64_t r = bid - tiles_m * full_n;
+        tm = r % tiles_m;
+        tn = full_n + r / tiles_m;
     }
     const int64_t m0 = tm * TM, n0 = tn << 8;
     const int64_t k_begin = SPLITK ? (int64_t)slice * k_per_slice : 0;

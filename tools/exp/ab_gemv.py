@@ -20,13 +20,13 @@ for i in range(64):
 x = torch.randn(1, K, generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16)
 out = torch.empty(1, N, dtype=torch.bfloat16, device=dev)
 ref = bnb.matmul_4bit(x, layers[0][0], layers[0][2])
-variants = [(0, 1), (1, 1), (2, 1), (0, 2), (2, 2)]
+variants = [(0, 1), (10, 1), (0, 2)]     # (10, 1) = k_gemv4_lean
 graphs = {}
 for (dec, nr) in variants:
     s = torch.cuda.current_stream().cuda_stream
     lib.exp_gemv(dec, nr, x.data_ptr(), layers[0][0].data_ptr(), layers[0][1].data_ptr(), out.data_ptr(), N, K, s)
     torch.cuda.synchronize()
-    print(f"dec {dec} nr {nr}: equal to the library result: {torch.equal(out, ref)}", flush=True)
+    print(f"dec {dec} nr {nr}: equal to the library result: {torch.equal(out, ref)}  max|d| {(out.float() - ref.float()).abs().max().item():.4g}  rel {((out.float() - ref.float()).norm() / ref.float().norm()).item():.3g}", flush=True)
     for hot in (False, True):
         gr = torch.cuda.CUDAGraph()
         side = torch.cuda.Stream()

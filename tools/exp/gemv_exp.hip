@@ -1,7 +1,7 @@
 // gemv_exp.hip — A/B harness for the M = 1 GEMV decode flavours (gemv4.h DEC = 0 / 1 / 2), bf16, NF4, plain absmax.
 #include <cstdarg>
 #include <cstdio>
-#include "../../mps_bitsandbytes_amd/csrc/gemv4.h"
+#include "../../mps_bitsandbytes_amd/csrc/gemv4_lean.h"
 namespace mbnb {
 void set_error(const char *, ...) {}
 void set_kernel_name(const char *) {}
@@ -21,6 +21,11 @@ extern "C" int exp_gemv(int dec, int nr, const void *X, const uint8_t *packed, c
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bf16_t *x = static_cast<const bf16_t *>(X);
     bf16_t *o = static_cast<bf16_t *>(out);
+    if (dec == 10) {    // k_gemv4_lean (K = 4096)
+        hipLaunchKernelGGL((k_gemv4_lean<bf16_t, bf16_t, MBNB_NF4, false, 2>), dim3((unsigned)((N + 3) / 4)), dim3(256), (size_t)K * 2, st, x, packed, am,
+                           (const bf16_t *)nullptr, o, N, K);
+        return (int)hipGetLastError();
+    }
     if (nr == 1) { if (dec == 0) return run<0, 1>(x, packed, am, o, N, K, st); if (dec == 1) return run<1, 1>(x, packed, am, o, N, K, st); return run<2, 1>(x, packed, am, o, N, K, st); }
     if (dec == 0) return run<0, 2>(x, packed, am, o, N, K, st); if (dec == 1) return run<1, 2>(x, packed, am, o, N, K, st); return run<2, 2>(x, packed, am, o, N, K, st);
 }
