@@ -17,6 +17,7 @@
 
 #include "gemm256.h"
 #include "gemv4.h"
+#include "gemv4_lean.h"
 
 namespace mbnb {
 
@@ -302,6 +303,21 @@ static int launch_matmul4(const void *A, int64_t M, int64_t K, const uint8_t *pa
             hipLaunchKernelGGL((k_gemv4<T, OutT, QT, NESTED, MT, NR, KU, false>), grid, dim3(256), 0, st, x, packed, \
                                am, b, o, M, N, K, K_weight, sh);                                                    \
     } while (0)
+            // M = 1, blocksize 64, K = 2048 / 4096 / 8192 (round 3): k_gemv4_lean -- the same arithmetic with the per-wave fixed cost
+            // cut (480 instead of 627 instructions per wave: buffer descriptors instead of 64-bit address VALU, table from
+            // constant memory, DPP reduction, no next-trip ring); bit-equal outputs, 5.25 -> 5.08 us per rotating 4096^2 layer,
+            // 4.67 -> 4.24 us on a cache-resident one (profiles/r03_gemv_lean_ab.txt)
+            if constexpr (std::is_same<OutT, T>::value) {
+                if (M == 1 && blocksize == 64 && K_weight == K && N < 8192 && (K == 2048 || K == 4096 || K == 8192) &&
+                    (!NESTED || (am.bs2 > 0 && (am.bs2 & (am.bs2 - 1)) == 0 && (reinterpret_cast<uintptr_t>(am.i8) & 3) == 0))) {
+                    const dim3 grid((unsigned)((N + 3) / 4));
+                    if (K == 2048) hipLaunchKernelGGL((k_gemv4_lean<T, OutT, QT, NESTED, 1>), grid, dim3(256), (size_t)K * 2, st, x, packed, am, b, o, N, K);
+                    else if (K == 4096) hipLaunchKernelGGL((k_gemv4_lean<T, OutT, QT, NESTED, 2>), grid, dim3(256), (size_t)K * 2, st, x, packed, am, b, o, N, K);
+                    else hipLaunchKernelGGL((k_gemv4_lean<T, OutT, QT, NESTED, 4>), grid, dim3(256), (size_t)K * 2, st, x, packed, am, b, o, N, K);
+                    set_kernel_name("gemv");
+                    return check_launch("matmul_4bit(gemv lean)");
+                }
+            }
             // M = 1: two rows per wave once there are enough rows to fill the chip twice over (4 KiB of packed
             // weights in flight per wave: +12 % streaming rate at N >= 8192, tools/gemv_sweep.py)
             if (M == 1 && N >= 8192) MBNB_GEMV(1, 2, 2);

@@ -1272,3 +1272,26 @@ def test_matmul_in_launch_decode_equals_the_two_launch_path(M, N, K, dt, qt, wit
         assert _native.last_kernel() == "dq_inlaunch"
         assert torch.equal(y, y_ref)
     assert bnb.functional.in_launch_errors() == 0
+
+
+@pytest.mark.parametrize("N,K,dt,qt,dq,with_bias", [(4096, 4096, torch.bfloat16, "nf4", False, False), (4096, 4096, torch.float16, "nf4", True, True),
+                                                     (1000, 2048, torch.bfloat16, "fp4", False, True), (515, 8192, torch.float16, "nf4", False, False),
+                                                     (4096, 8192, torch.bfloat16, "nf4", True, False)])
+def test_matmul_m1_lean_gemv_vs_oracle(N, K, dt, qt, dq, with_bias):
+    """M = 1 at K = 2048 / 4096 / 8192, blocksize 64 -> k_gemv4_lean (round 3).  VERDICT r2's thin spot: the bf16 instantiation the
+    bench's `gemv` object times at 4096^2 against the oracle at that size; plus FP4, double-quantised absmax, bias, a ragged N
+    (the last workgroup's idle waves) and the 2- and 8-chunk rows.  And the row is independent of its neighbours: the same row
+    through the M = 2 kernel agrees."""
+    W = synthetic.normal((N, K), dt, seed=421, std=0.05 if dq else 1.0)
+    x = synthetic.normal((1, K), dt, seed=422)
+    bias = synthetic.normal((N,), dt, seed=423) if with_bias else None
+    packed, st = bnb.quantize_4bit(W.to(DEV), blocksize=64, quant_type=qt, compress_statistics=dq)
+    y = bnb.matmul_4bit(x.to(DEV), packed, st, None if bias is None else bias.to(DEV))
+    assert _native.last_kernel() == "gemv"
+    op, oa, os2 = oracle.quantize_4bit(W, 64, qt, dq)
+    assert torch.equal(packed.cpu(), op)
+    ref = oracle.matmul_4bit(x, op, oa, (N, K), 64, qt, dt, bias, None, os2)
+    assert rel_fro(y.cpu(), ref) <= TOL[dt]
+    x2 = torch.cat([x, synthetic.normal((1, K), dt, seed=424)]).to(DEV)
+    y2 = bnb.matmul_4bit(x2, packed, st, None if bias is None else bias.to(DEV))
+    assert rel_fro(y2[:1].cpu(), y.cpu()) <= TOL[dt]
