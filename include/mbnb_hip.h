@@ -204,19 +204,35 @@ int mbnb_matmul_int8(const int8_t *A, const int8_t *B, const float *A_scales,
 /* MBNB_MATMUL_FUSED4: serve large blocksize-64 problems (>= 96 tiles of 256 x 256, K % 64 == 0, K_weight % 256 == 0) with the
  * four-wave fused decode + MFMA kernel (csrc/gemm_fused4.h): one launch, no scratch, the bits of the decode-once path. */
 #define MBNB_MATMUL_FUSED4 2
+/* flags of mbnb_matmul_4bit_sync only (described there); MBNB_MATMUL_GEMM_FIRST: with MBNB_MATMUL_SIDE_STREAM, launch the gated GEMM
+ * before the decoder (diagnostic). */
+#define MBNB_MATMUL_IN_WAVE 4
+#define MBNB_MATMUL_GEMM_FIRST 8
+#define MBNB_MATMUL_SIDE_STREAM 16
+#define MBNB_MATMUL_SPLIT_DECODE 32
 int mbnb_matmul_4bit_ex(const void *A, int64_t M, int64_t K, const uint8_t *packed,
                         const mbnb_absmax *absmax, int64_t N, int64_t K_weight, int blocksize,
                         int quant_type, int w_dtype, const void *bias, int out_dtype, void *out,
                         void *workspace, int64_t workspace_bytes, int flags, void *stream);
 
-/* mbnb_matmul_4bit_ex with a SYNC area: where mbnb_matmul_4bit_sync_bytes(...) > 0 (blocksize 64, plain f32 absmax, 3840 < M
- * <= 4096 rows, K % 512 == 0, K_weight == K, at most one 256 x 256 tile per compute unit of the device) and the workspace holds
- * the N x K x 2-byte scratch, the weight is decoded ONCE INSIDE the GEMM launch (csrc/gemm_dq.h: one launch instead of
- * dequantize_4bit + dense GEMM; same bits).  `sync`: mbnb_matmul_4bit_sync_bytes bytes of device memory that are ZERO on entry;
- * the launch leaves them zero, so one buffer per (device, stream) serves every call -- it must not be shared by launches that
- * can run concurrently.  Word [tiles_n * 66] of it is an error word: non-zero after a launch = a hand-off timed out (some
- * workgroup was not resident for seconds) and that call's output is not valid.  sync == NULL, or a shape the path does not
- * serve: exactly mbnb_matmul_4bit_ex. */
+/* mbnb_matmul_4bit_ex with a SYNC area (the two steps of functional.py:753-767 -- dequantise, then multiply -- overlapped instead
+ * of back to back; same bits as dequantize_4bit + dense GEMM).  Where mbnb_matmul_4bit_sync_bytes(...) > 0 and the workspace holds
+ * the N x K_weight x 2-byte scratch:
+ *   default                    csrc/gemm_beside.h: the dequantise pass as a 28-register kernel whose waves are resident BESIDE the
+ *                              GEMM's, slabs of 512 k handed over through agent-scope flags (blocksize 64, plain or double-quantised
+ *                              absmax with a power-of-two second blocksize, K % 512 == 0, K >= 1024, N * K_weight * 2 < 2^31, shapes
+ *                              whose dense plan is unsplit 256 x 256 tiles).  Launch arrangement: one stream (decoder, then the GEMM
+ *                              as an any-order launch); MBNB_MATMUL_SIDE_STREAM: decoder on a library-owned side stream forked from
+ *                              / joined to `stream` by events; MBNB_MATMUL_SPLIT_DECODE: first slab in `stream`, the rest on the
+ *                              side stream (joined only inside a stream capture: the GEMM cannot finish before the decoder's last
+ *                              store has left).
+ *   MBNB_MATMUL_IN_WAVE        csrc/gemm_dq.h: ONE launch, the GEMM's own waves decode (plain f32 absmax, 3840 < M <= 4096 rows,
+ *                              K_weight == K, at most one 256 x 256 tile per compute unit of the device).
+ * `sync`: mbnb_matmul_4bit_sync_bytes bytes of device memory that are ZERO on entry; the call's work leaves them zero, so one
+ * buffer per (device, stream) serves every call -- it must not be shared by calls that can run concurrently.  Word
+ * [tiles_n * 66] of it is an error word: non-zero afterwards = a hand-off timed out (seconds) and that call's output is not valid.
+ * sync == NULL, or a shape the selected form does not serve: exactly mbnb_matmul_4bit_ex.  Neither form is faster than the two
+ * launches on ROCm 7.2 / gfx950: mbnb_matmul_4bit_ex stays the default of the Python mirror. */
 int64_t mbnb_matmul_4bit_sync_bytes(int64_t M, int64_t N, int64_t K, int64_t K_weight, int blocksize);
 int mbnb_matmul_4bit_sync(const void *A, int64_t M, int64_t K, const uint8_t *packed,
                           const mbnb_absmax *absmax, int64_t N, int64_t K_weight, int blocksize,

@@ -77,6 +77,9 @@ int64_t gemm_dense_workspace_bytes(int64_t, int64_t, int64_t, int64_t);
 int64_t gemm_dq_sync_bytes(int64_t, int64_t, int64_t, int64_t, int);
 int matmul_4bit_dq_path(const void *, int64_t, int64_t, const uint8_t *, const AbsmaxView &, int64_t, int64_t, int, int, int, const void *, int, void *,
                         void *, int64_t, void *, int64_t, hipStream_t);
+int64_t gemm_beside_sync_bytes(int64_t, int64_t, int64_t, int64_t, int);
+int matmul_4bit_beside_path(const void *, int64_t, int64_t, const uint8_t *, const AbsmaxView &, int64_t, int64_t, int, int, int, const void *, int, void *,
+                            void *, int64_t, void *, int64_t, hipStream_t, int);
 bool gemm_dense_shape(int64_t, int64_t, int64_t, int64_t);
 int64_t gemm_dense_slices(int64_t, int64_t, int64_t);
 int gemm_dense_direct(const void *, const void *, int, const void *, int, void *, int64_t, int64_t, int64_t, int64_t, float *, int64_t, int,
@@ -253,7 +256,8 @@ int mbnb_matmul_4bit_ex(const void *A, int64_t M, int64_t K, const uint8_t *pack
 
 int64_t mbnb_matmul_4bit_sync_bytes(int64_t M, int64_t N, int64_t K, int64_t K_weight, int blocksize) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
-    return gemm_dq_sync_bytes(M, N, K, K_weight, blocksize);
+    const int64_t a = gemm_dq_sync_bytes(M, N, K, K_weight, blocksize), b = gemm_beside_sync_bytes(M, N, K, K_weight, blocksize);
+    return a > b ? a : b;
 }
 
 int mbnb_matmul_4bit_sync(const void *A, int64_t M, int64_t K, const uint8_t *packed, const mbnb_absmax *absmax, int64_t N,
@@ -264,10 +268,16 @@ int mbnb_matmul_4bit_sync(const void *A, int64_t M, int64_t K, const uint8_t *pa
         pow2(blocksize) && K_weight >= K) {
         AbsmaxView v;
         if (int rc = absmax_view(absmax, "matmul_4bit", v)) return rc;
-        const int rc = matmul_4bit_dq_path(A, M, K, packed, v, N, K_weight, blocksize, quant_type, w_dtype, bias, out_dtype, out, workspace,
-                                           workspace_bytes, sync, sync_bytes, static_cast<hipStream_t>(stream));
+        int rc = MBNB_NOT_APPLICABLE;
+        if (!(flags & MBNB_MATMUL_IN_WAVE))
+            rc = matmul_4bit_beside_path(A, M, K, packed, v, N, K_weight, blocksize, quant_type, w_dtype, bias, out_dtype, out, workspace,
+                                         workspace_bytes, sync, sync_bytes, static_cast<hipStream_t>(stream), ((flags & MBNB_MATMUL_SPLIT_DECODE) ? 4 : 0) | ((flags & MBNB_MATMUL_SIDE_STREAM) ? 2 : 0) | ((flags & MBNB_MATMUL_GEMM_FIRST) ? 1 : 0));
+        else
+            rc = matmul_4bit_dq_path(A, M, K, packed, v, N, K_weight, blocksize, quant_type, w_dtype, bias, out_dtype, out, workspace,
+                                     workspace_bytes, sync, sync_bytes, static_cast<hipStream_t>(stream));
         if (rc != MBNB_NOT_APPLICABLE) return rc;
     }
+    flags &= ~(MBNB_MATMUL_IN_WAVE | MBNB_MATMUL_GEMM_FIRST | MBNB_MATMUL_SIDE_STREAM | MBNB_MATMUL_SPLIT_DECODE);
     return mbnb_matmul_4bit_ex(A, M, K, packed, absmax, N, K_weight, blocksize, quant_type, w_dtype, bias, out_dtype, out, workspace,
                                workspace_bytes, flags, stream);
 }

@@ -73,6 +73,19 @@ DECODE_ONCE = True
 # 106-107 us against 105 us for the two launches (profiles/r03_dq_ablation.txt: the hand-off's write-through stores, agent-scope
 # atomics and the 3.6 us start-up eat what the hidden dequantise pass saves), and it needs every workgroup resident at once.
 DECODE_IN_LAUNCH = False
+# Large M, blocksize 64, K % 512 == 0: the dequantise pass as a 28-register kernel whose waves run BESIDE the GEMM's on the same SIMDs,
+# slabs handed over through flags (csrc/gemm_beside.h; same bits).  OFF by default: the kernels overlap as intended, but starting two
+# kernels concurrently costs more than the pass on this runtime (a dependency between two queues ~8 us, the any-order launch flag
+# not honoured on gfx9): 105-115 us against 100-104 for the two launches (profiles/r03_beside_ab.txt).
+# BESIDE_SIDE_STREAM / BESIDE_SPLIT / BESIDE_GEMM_FIRST pick the launch arrangement (flags of mbnb_matmul_4bit_sync).
+DECODE_BESIDE = False
+BESIDE_SIDE_STREAM = False
+BESIDE_SPLIT = False
+BESIDE_GEMM_FIRST = False
+MATMUL_IN_WAVE = 4
+MATMUL_GEMM_FIRST = 8
+MATMUL_SIDE_STREAM = 16
+MATMUL_SPLIT_DECODE = 32
 _SYNC_AREAS: dict = {}
 
 
@@ -602,7 +615,14 @@ def matmul_4bit(
     flags = 0 if DECODE_ONCE else MATMUL_FUSED_ONLY
     # Where the shape allows it the weight is decoded once INSIDE the GEMM launch (csrc/gemm_dq.h): the launch needs a small
     # sync area that is zero on entry and that it leaves zero -- one persistent buffer per (device, stream), made on first use.
-    sync = _sync_area(A.device, M, N, K, K_weight, blocksize) if (DECODE_ONCE and DECODE_IN_LAUNCH and ws is not None and quant_state.state2 is None) else None
+    # DECODE_BESIDE: the dequantise pass as a 32-register kernel on a side stream, resident beside the GEMM's waves (csrc/gemm_beside.h).
+    sync = None
+    if DECODE_ONCE and ws is not None and (DECODE_BESIDE or (DECODE_IN_LAUNCH and quant_state.state2 is None)):
+        sync = _sync_area(A.device, M, N, K, K_weight, blocksize)
+        if sync is not None and not DECODE_BESIDE:
+            flags |= MATMUL_IN_WAVE
+        elif sync is not None:
+            flags |= (MATMUL_SPLIT_DECODE if BESIDE_SPLIT else 0) | (MATMUL_SIDE_STREAM if BESIDE_SIDE_STREAM else 0) | (MATMUL_GEMM_FIRST | MATMUL_SIDE_STREAM if BESIDE_GEMM_FIRST else 0)
     with torch.cuda.device(A.device):
         if sync is not None:
             check(_native.lib().mbnb_matmul_4bit_sync(

@@ -1295,3 +1295,29 @@ def test_matmul_m1_lean_gemv_vs_oracle(N, K, dt, qt, dq, with_bias):
     x2 = torch.cat([x, synthetic.normal((1, K), dt, seed=424)]).to(DEV)
     y2 = bnb.matmul_4bit(x2, packed, st, None if bias is None else bias.to(DEV))
     assert rel_fro(y2[:1].cpu(), y.cpu()) <= TOL[dt]
+
+
+@pytest.mark.parametrize("M,N,K,dt,qt,dq,with_bias", [(4096, 4096, 4096, torch.bfloat16, "nf4", False, False), (4000, 2560, 2048, torch.float16, "fp4", False, True),
+                                                      (3900, 2500, 2048, torch.bfloat16, "nf4", True, True), (4096, 11008, 1024, torch.bfloat16, "nf4", True, False)])
+@pytest.mark.parametrize("mode", ["one_stream", "two_streams", "split"])
+def test_matmul_decode_beside_equals_the_two_launch_path(M, N, K, dt, qt, dq, with_bias, mode, monkeypatch):
+    """csrc/gemm_beside.h (round 3; functional.DECODE_BESIDE, off by default): the dequantise pass as a 28-register kernel whose waves
+    fit BESIDE k_gemm_dense's on a SIMD, handing slabs of 512 k to the gated GEMM through agent-scope flags -- in the three launch
+    arrangements the library has (one stream; two streams with fork / join; first slab in the caller's stream, the rest beside).  Same
+    Wd bits and pipeline as dequantize_4bit + k_gemm_dense -> same output bits; a different weight through the same scratch on the
+    second call (no stale line of the previous one); ragged M and N (a partial tile column has fewer decoders); flags back to zero."""
+    monkeypatch.setattr(bnb.functional, "BESIDE_SIDE_STREAM", mode == "two_streams")
+    monkeypatch.setattr(bnb.functional, "BESIDE_SPLIT", mode == "split")
+    x = synthetic.normal((M, K), dt, seed=432).to(DEV)
+    bias = synthetic.normal((N,), dt, seed=433).to(DEV) if with_bias else None
+    for rep in range(3):
+        W = synthetic.normal((N, K), dt, seed=431 + 10 * rep, std=0.05 if dq else 1.0)
+        packed, st = bnb.quantize_4bit(W.to(DEV), blocksize=64, quant_type=qt, compress_statistics=dq)
+        monkeypatch.setattr(bnb.functional, "DECODE_BESIDE", False)
+        y_ref = bnb.matmul_4bit(x, packed, st, bias)
+        assert _native.last_kernel().startswith("dequant+dense")
+        monkeypatch.setattr(bnb.functional, "DECODE_BESIDE", True)
+        y = bnb.matmul_4bit(x, packed, st, bias)
+        assert _native.last_kernel() == "decode_beside+gated"
+        assert torch.equal(y, y_ref)
+    assert bnb.functional.in_launch_errors() == 0

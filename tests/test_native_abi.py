@@ -64,11 +64,16 @@ def test_gemm_dense_and_matmul_ex_argument_errors():
     assert lib.mbnb_gemm_dense(one, one, 1, None, 1, one, 256, 256, 256, 128, None, 0, 1, None) == -2          # ldw < K
     assert lib.mbnb_gemm_dense(one, one, 1, None, 1, one, 256, 256, 256, 256, None, 0, 2, None) == -1          # split without workspace
     assert b"workspace" in lib.mbnb_last_error()
-    assert lib.mbnb_gemm_dense(one, one, 1, None, 1, one, 256, 256, 256, 256, None, 0, 1 | (3 << 8), None) == -1   # tile rows 384
+    assert lib.mbnb_gemm_dense(one, one, 1, None, 1, one, 256, 256, 256, 256, None, 0, 1 | (4 << 8), None) == -1   # tile code 4 (3 = 128 x 128 since round 3)
+    assert b"tile code" in lib.mbnb_last_error()
+    assert lib.mbnb_gemm_dense(one, one, 1, None, 1, one, 256, 256, 256, 256, one, 1 << 30, 2 | (3 << 8), None) == -1   # the 128 x 128 tile takes no K slices
+    assert lib.mbnb_gemm_dense(one, one, 1, None, 1, one, 256, 256, 128, 128, None, 0, 1 | (3 << 8), None) == -1        # ... and needs K >= 192
     assert lib.mbnb_gemm_dense(ctypes.c_void_p(8), one, 1, None, 1, one, 256, 256, 256, 256, None, 0, 1, None) == -1  # misaligned A
     rc = lib.mbnb_matmul_4bit_ex(one, 4, 64, one, None, 8, 64, 64, 0, 0, None, 0, one, None, 0, 0, None)
     assert rc == -1 and b"absmax" in lib.mbnb_last_error()
     rc = lib.mbnb_matmul_4bit_ex(one, 4, 64, one, None, 8, 64, 64, 0, 0, None, 0, one, None, 0, 6, None)
+    assert rc == -1 and b"flags" in lib.mbnb_last_error()
+    rc = lib.mbnb_matmul_4bit_ex(one, 4, 64, one, None, 8, 64, 64, 0, 0, None, 0, one, None, 0, 32, None)   # a flag of mbnb_matmul_4bit_sync only
     assert rc == -1 and b"flags" in lib.mbnb_last_error()
 
 
@@ -93,7 +98,8 @@ def test_workspace_size_functions_are_pure_host_code():
     assert full(384, 4096, 4096) > 4096 * 4096 * 2          # 1.57 M outputs: the weight + split-K partials
     assert full(4096, 4096, 4096) == 4096 * 4096 * 2        # the dequantised weight, no split (256 tiles)
     assert full(32768, 4096, 4096) == 4096 * 4096 * 2
-    assert full(1024, 4096, 4096) == 4096 * 4096 * 2 + 2 * 1024 * 4096 * 4   # 128 tiles of 256 x 128 -> 2 slices of f32 partials
+    assert full(1024, 4096, 4096) == 4096 * 4096 * 2        # round 3: 256 tiles of 128 x 128 in one round (gemm_dense128.h) instead of 2 K slices
+    assert full(512, 2048, 8192) == 2048 * 8192 * 2 + 8 * 512 * 2048 * 4   # 64 tiles of 128 x 128, long K: 8 slices of f32 partials
     assert full(2048, 4096, 4096) == 4096 * 4096 * 2        # from 96 tiles up: never split (row bits independent of M)
     assert full(4096, 4096, 4104) == sk(4096, 4096, 4104)   # K % 64 != 0: fused kernels only
     kw = lib.mbnb_matmul_4bit_workspace_bytes_kw
