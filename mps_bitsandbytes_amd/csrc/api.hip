@@ -72,6 +72,7 @@ int linear_fp8_dispatch(const void *, int, int64_t, int64_t, const uint8_t *, co
 int64_t matmul4_splitk_slices(int64_t, int64_t, int64_t);
 int64_t gemm_mid_workspace_bytes(int64_t, int64_t, int64_t);
 int64_t gemm_small_workspace_bytes(int64_t, int64_t, int64_t, int64_t);
+int64_t gemm_small8_workspace_bytes(int64_t, int64_t, int64_t);
 int64_t gemm_f32_workspace_bytes(int64_t, int64_t, int64_t, int64_t);
 int64_t gemm_dense_workspace_bytes(int64_t, int64_t, int64_t, int64_t);
 int64_t gemm_dq_sync_bytes(int64_t, int64_t, int64_t, int64_t, int);
@@ -328,7 +329,7 @@ int64_t mbnb_linear_int8_workspace_bytes(int64_t M, int64_t N, int64_t K) {
     const int64_t s = matmul4_splitk_slices(M, N, K);
     const int64_t a = s > 1 ? s * ((M + 127) / 128) * ((N + 127) / 128) * 65536 : 0;   // slices x tiles x 128 x 128 f32
     const int64_t c = gemm_dense_workspace_bytes(M, N, K, K);   // large M: the dequantised weight (+ split-K partials)
-    const int64_t d = gemm_small_workspace_bytes(M, N, K, K);   // 32 < M <= 256: slices x M x N f32 (gemm_small8.h)
+    const int64_t d = gemm_small8_workspace_bytes(M, N, K);   // 32 < M <= 384: slices x M x N f32 (gemm_small8.h)
     const int64_t ac = a > c ? a : c;
     return ac > d ? ac : d;
 }

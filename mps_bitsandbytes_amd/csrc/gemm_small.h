@@ -36,7 +36,10 @@ template <int N, class F> __device__ __forceinline__ void gs_static_for(F &&f) {
 
 template <int MF> constexpr int gemm_small_lds_bytes() { return 2 * 16 * MF * 512; }
 
-template <typename T, bool NESTED, int MF, int NF = 1>
+// MAXS_: steps of a slice whose weights the prologue loads into registers (12 registers per step and fragment); 0 = 8 (NF = 1) / 4
+// (NF = 2).  16 (round 3): K = 4096 in ONE slice -- 384 < M <= 512 rows on a 4096-wide layer are 256 workgroups in one round with
+// no partials and no reduction launch.
+template <typename T, bool NESTED, int MF, int NF = 1, int MAXS_ = 0>
 __global__ __launch_bounds__(256, 1) void k_gemm_small(const T *__restrict__ X, const uint8_t *__restrict__ packed, AbsmaxView am,
                                                        const T *__restrict__ bias, void *__restrict__ out_v, int out_dtype,
                                                        float *__restrict__ partial, int64_t M, int64_t N, int64_t K,
@@ -48,7 +51,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_small(const T *__restrict__ X, 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, kc = lane >> 4;
-    constexpr int MAXS = NF == 1 ? 8 : 4;     // steps of a slice: its weights live in registers
+    constexpr int MAXS = MAXS_ ? MAXS_ : (NF == 1 ? 8 : 4);     // steps of a slice: its weights live in registers
     const int64_t n0 = (int64_t)blockIdx.x * (64 * NF), m0 = (int64_t)blockIdx.z * ROWS;
     const int slice = blockIdx.y;
     const int64_t k_begin = (int64_t)slice * k_per_slice;

@@ -4,28 +4,37 @@
 
 namespace mbnb {
 
-bool gemm_small_shape(int64_t M, int64_t N, int64_t K, int64_t K_weight) {
+static bool small_shape_up_to(int64_t M, int64_t N, int64_t K, int64_t K_weight, int64_t max_m) {
     // from 33 rows (17 for layers of more than 16 Mi weights) the weight-streaming skinny kernel loses: 64 x 4096 x 4096 12.8 us
     // here, 18.5 there; 32 x 4096 x 4096 11.8 vs 11.7; 32 x 11008 x 4096 21.7 vs 31.0 (tools/exp/small_check.py)
-    return (M > 32 || (M > 16 && N * K > ((int64_t)1 << 24))) && M <= 384 && K % 256 == 0 && K >= 512 && K <= 16 * 2048 && K_weight % 256 == 0 && N >= 64 &&
+    return (M > 32 || (M > 16 && N * K > ((int64_t)1 << 24))) && M <= max_m && K % 256 == 0 && K >= 512 && K <= 16 * 2048 && K_weight % 256 == 0 && N >= 64 &&
            256 * K * 2 < ((int64_t)1 << 31);
 }
+// 4-bit weights: up to 512 rows (round 3: k_gemm_small<.., MAXS_ = 16> holds 16 steps of weights in registers -- K = 4096 in one slice,
+// 384 < M <= 512 on a 4096-wide layer = 256 workgroups, one round, no partials); the W8A16 form (gemm_small8.h) keeps 384 rows / 8 steps.
+bool gemm_small_shape(int64_t M, int64_t N, int64_t K, int64_t K_weight) { return small_shape_up_to(M, N, K, K_weight, 512); }
+bool gemm_small8_shape(int64_t M, int64_t N, int64_t K) { return small_shape_up_to(M, N, K, K, 384); }
 // Plan = (NF: n-fragments per wave -> 64 NF weight rows per workgroup; K slices).  The kernel is bound by what a workgroup takes
 // in (activation tile 16 MF rows x 256 k per step against 32 NF bytes of weights per lane), so per step a workgroup costs
 // about  0.4 us + its activation KiB / 55 GB/s  (small_check.py: 64 KiB -> 1.6 us, 32 KiB -> 1.0 us), a slice pays a prologue
 // of ~2.5 us, and every extra slice adds M x N x 4 bytes of partials written and read (6 TB/s).
 struct SmallPlan { int nf; int64_t slices; };
-SmallPlan gemm_small_plan(int64_t M, int64_t N, int64_t K) {
+SmallPlan gemm_small_plan(int64_t M, int64_t N, int64_t K, int maxs_mf8 = 16) {
     const int64_t mf = M > 64 ? 8 : 4, mt = (M + 16 * mf - 1) / (16 * mf), steps = K / 256;
     SmallPlan best{1, 1};
     double best_t = 1e30;
     for (int nf = 1; nf <= 1; nf++) {   // nf = 2 (128 weight rows per workgroup) measured slower on every shape of small_check.py
-        const int64_t wgs = ((N + 64 * nf - 1) / (64 * nf)) * mt, maxs = nf == 1 ? 8 : 4;
+        const int64_t wgs = ((N + 64 * nf - 1) / (64 * nf)) * mt, maxs = nf == 1 ? (mf == 8 ? maxs_mf8 : 8) : 4;   // 16: k_gemm_small<.., MAXS_ = 16>
         const double step_us = 0.4 * nf + (double)(mf * 8) / 55.0;     // KiB of activations per step = 16 mf x 512 / 1024 = 8 mf
         for (int64_t s = 1; s <= 16 && s <= steps; s++) {
             const int64_t per = (steps + s - 1) / s;
             if (per > maxs) continue;
-            const double t = (double)((wgs * s + 255) / 256) * (2.5 + (double)per * step_us) + (s > 1 ? 8.0 * (double)s * (double)M * (double)N / 6.0e6 + 2.0 : 0.0);
+            // more than 8 steps per slice = the 16-step instantiation: 2.06 us per step measured (512 x 4096 x 4096 in one round: 35.5 us)
+            const double su = per > 8 ? step_us * 1.32 : step_us;
+            // the reduction launch: 3-4 us + the boundary (288 x 4096 x 4096 in two slices: 38.1 us); the plans up to 256 rows were tuned
+            // with 2.0 and keep it
+            const double split_fixed = M > 256 ? 5.0 : 2.0;
+            const double t = (double)((wgs * s + 255) / 256) * (2.5 + (double)per * su) + (s > 1 ? 8.0 * (double)s * (double)M * (double)N / 6.0e6 + split_fixed : 0.0);
             if (t < best_t - 1e-9) {
                 best_t = t;
                 best = SmallPlan{nf, s};
@@ -35,16 +44,32 @@ SmallPlan gemm_small_plan(int64_t M, int64_t N, int64_t K) {
     return best;
 }
 int64_t gemm_small_slices(int64_t M, int64_t N, int64_t K) { return gemm_small_plan(M, N, K).slices; }
+// 256 < M <= 512 where the planned workgroups fit the chip in ONE round: k_gemm_small beats dequantise + dense there (512 x 4096^2
+// 35.6 vs 40.6 us, 512 x 4096 x 2048 19.5 vs 27.5, 512 x 2048 x 4096 24.9 vs 34.8; two rounds lose: 400 x 5120 x 4096 56 vs 42,
+// tools/exp/ab_small16.py, profiles/r03_small16_ab.txt), so matmul_4bit_dispatch tries it BEFORE the decode-once path.  A row's bits
+// then depend on M below 513 rows (another summation order than the dense tiles'), as they always did below 257.
+bool gemm_small_one_round(int64_t M, int64_t N, int64_t K, int64_t K_weight, int64_t ws_bytes) {
+    if (M <= 256 || !gemm_small_shape(M, N, K, K_weight)) return false;
+    const SmallPlan plan = gemm_small_plan(M, N, K);
+    const int64_t wgs = ((N + 63) / 64) * ((M + 127) / 128) * plan.slices;
+    return wgs <= 256 && (plan.slices == 1 || ws_bytes >= plan.slices * M * N * 4);
+}
+int64_t gemm_small8_slices(int64_t M, int64_t N, int64_t K) { return gemm_small_plan(M, N, K, 8).slices; }
+int64_t gemm_small8_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+    if (!gemm_small8_shape(M, N, K)) return 0;
+    const int64_t s = gemm_small8_slices(M, N, K);
+    return s > 1 ? s * M * N * 4 : 0;
+}
 int64_t gemm_small_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t K_weight) {
     if (!gemm_small_shape(M, N, K, K_weight)) return 0;
     const int64_t s = gemm_small_slices(M, N, K);
     return s > 1 ? s * M * N * 4 : 0;
 }
 
-template <typename T, typename OutT, bool NESTED, int MF, int NF>
+template <typename T, typename OutT, bool NESTED, int MF, int NF, int MAXS = 0>
 static int launch_gemm_small_mf(const T *x, const uint8_t *packed, const AbsmaxView &am, const T *bias, OutT *out, int64_t M, int64_t N,
                                 int64_t K, int64_t K_weight, int qt, int bs_shift, float *ws, int64_t ws_bytes, int64_t slices, hipStream_t st) {
-    auto kern = k_gemm_small<T, NESTED, MF, NF>;
+    auto kern = k_gemm_small<T, NESTED, MF, NF, MAXS>;
     constexpr int lds = gemm_small_lds_bytes<MF>();
     if (int rc = ensure_dyn_lds(reinterpret_cast<const void *>(kern), lds, "matmul_4bit(small)")) return rc;
     const int64_t steps = K / 256;
@@ -71,7 +96,7 @@ int launch_gemm_small(const T *x, const uint8_t *packed, const AbsmaxView &am, c
                       int64_t K_weight, int qt, int bs_shift, float *ws, int64_t ws_bytes, hipStream_t st) {
     SmallPlan plan = gemm_small_plan(M, N, K);
     if (plan.slices > 1 && (ws == nullptr || ws_bytes < plan.slices * M * N * 4 || (reinterpret_cast<uintptr_t>(ws) & 15))) {
-        if (K / 256 > 8) return MBNB_NOT_APPLICABLE;
+        if (K / 256 > (M > 64 ? 16 : 8)) return MBNB_NOT_APPLICABLE;
         plan = SmallPlan{1, 1};
     }
 #define MBNB_SMALL(MF, NF) return launch_gemm_small_mf<T, OutT, NESTED, MF, NF>(x, packed, am, bias, out, M, N, K, K_weight, qt, bs_shift, ws, ws_bytes, plan.slices, st)
@@ -80,6 +105,8 @@ int launch_gemm_small(const T *x, const uint8_t *packed, const AbsmaxView &am, c
         MBNB_SMALL(4, 1);
     }
     if (plan.nf == 2) MBNB_SMALL(8, 2);
+    if ((K / 256 + plan.slices - 1) / plan.slices > 8)
+        return launch_gemm_small_mf<T, OutT, NESTED, 8, 1, 16>(x, packed, am, bias, out, M, N, K, K_weight, qt, bs_shift, ws, ws_bytes, plan.slices, st);
     MBNB_SMALL(8, 1);
 #undef MBNB_SMALL
 }

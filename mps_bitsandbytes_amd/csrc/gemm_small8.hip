@@ -4,16 +4,16 @@
 
 namespace mbnb {
 
-bool gemm_small_shape(int64_t M, int64_t N, int64_t K, int64_t K_weight);
-int64_t gemm_small_slices(int64_t M, int64_t N, int64_t K);
+bool gemm_small8_shape(int64_t M, int64_t N, int64_t K);
+int64_t gemm_small8_slices(int64_t M, int64_t N, int64_t K);
 
 // Returns MBNB_NOT_APPLICABLE when the kernel cannot serve the call.
 template <typename T, int WF>
 int launch_gemm_small8(const T *x, const uint8_t *W, const float *scales, const T *bias, T *out, int64_t M, int64_t N, int64_t K, float *ws,
                        int64_t ws_bytes, hipStream_t st) {
-    if (!gemm_small_shape(M, N, K, K)) return MBNB_NOT_APPLICABLE;
+    if (!gemm_small8_shape(M, N, K)) return MBNB_NOT_APPLICABLE;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(W)) & 15) return MBNB_NOT_APPLICABLE;
-    int64_t slices = gemm_small_slices(M, N, K);
+    int64_t slices = gemm_small8_slices(M, N, K);
     const int64_t steps = K / 256;
     if (slices > 1 && (ws == nullptr || ws_bytes < slices * M * N * 4 || (reinterpret_cast<uintptr_t>(ws) & 15))) {
         if (steps > 8) return MBNB_NOT_APPLICABLE;

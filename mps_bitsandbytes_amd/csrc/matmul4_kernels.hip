@@ -32,6 +32,7 @@ int launch_gemm_mid(const T *x, const typename Q4ProducerRT<T, NESTED>::Params &
                     int64_t N, int64_t K, float *ws, int64_t ws_bytes, int force_slices, hipStream_t st);
 bool gemm_mid_shape(int64_t M, int64_t N, int64_t K);
 bool gemm_small_shape(int64_t M, int64_t N, int64_t K, int64_t K_weight);
+bool gemm_small_one_round(int64_t M, int64_t N, int64_t K, int64_t K_weight, int64_t ws_bytes);
 template <typename T, typename OutT, bool NESTED>
 int launch_gemm_small(const T *, const uint8_t *, const AbsmaxView &, const T *, OutT *, int64_t, int64_t, int64_t, int64_t, int, int, float *,
                       int64_t, hipStream_t);
@@ -515,8 +516,13 @@ int matmul_4bit_dispatch(const void *A, int64_t M, int64_t K, const uint8_t *pac
         const int rc = matmul_4bit_fused4_path(A, M, K, packed, am, N, K_weight, blocksize, qt, w_dtype, bias, out_dtype, out, st);
         if (rc != MBNB_NOT_APPLICABLE) return rc;
     }
+    // 256 < M <= 512 rows that k_gemm_small serves in one round of workgroups stay fused (gemm_small.hip: gemm_small_one_round); the
+    // conditions of that branch of launch_matmul4 are repeated here so that nothing else is kept away from the decode-once path
+    const bool small_first = (w_dtype == MBNB_F16 || w_dtype == MBNB_BF16) && blocksize >= 32 && (K_weight % 32 == 0) && (K % 8 == 0) &&
+                             aligned16(A) && aligned16(packed) && (workspace == nullptr || (reinterpret_cast<uintptr_t>(workspace) & 15) == 0) &&
+                             gemm_small_one_round(M, N, K, K_weight, workspace ? ws_bytes : 0);
     // large M: decode the weight once into the workspace, then the dense MFMA GEMM (gemm_dense.hip)
-    if (!fused_only) {
+    if (!fused_only && !small_first) {
         const int rc = matmul_4bit_dense_path(A, M, K, packed, am, N, K_weight, blocksize, qt, w_dtype, bias, out_dtype, out, workspace,
                                               ws_bytes, st);
         if (rc != MBNB_NOT_APPLICABLE) return rc;

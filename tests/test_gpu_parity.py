@@ -164,7 +164,7 @@ def test_matmul_skinny_path(case):
 
 @pytest.mark.parametrize("case", [
     dict(M=256, N=4096, K=4096, dt=torch.bfloat16), dict(M=200, N=1000, K=1024, dt=torch.float16, cs=True, qt="fp4", bs=128),
-    dict(M=512, N=4096, K=2048, dt=torch.bfloat16, cd=torch.float32), dict(M=1024, N=2048, K=4096, dt=torch.float16),
+    dict(M=640, N=4096, K=2048, dt=torch.bfloat16, cd=torch.float32), dict(M=1024, N=2048, K=4096, dt=torch.float16),
     dict(M=40, N=11008, K=4096, dt=torch.bfloat16, cs=True, bs=32),
 ])
 def test_matmul_splitk_path(case, monkeypatch):
@@ -173,7 +173,7 @@ def test_matmul_splitk_path(case, monkeypatch):
     monkeypatch.setattr(bnb.functional, "DECODE_ONCE", False)   # the fused split-K kernels (callers without the N x K scratch)
     c = dict(case)
     M, N, K = c["M"], c["N"], c["K"]
-    want = "mfma_small_splitk" if (M <= 256 and K % 256 == 0 and K >= 512) else "mfma128_splitk"   # <= 256 rows: gemm_small.h
+    want = "mfma_small_splitk" if (M <= 512 and K % 256 == 0 and K >= 512) else "mfma128_splitk"   # <= 512 rows: gemm_small.h
     assert _oracle_vs_gpu_matmul(c.pop("M"), c.pop("N"), c.pop("K"), c.pop("dt"), seed=28, **c) == want
     # run-to-run determinism (fixed slice order, no atomics)
     W = synthetic.normal((N, K), torch.bfloat16, seed=1, std=0.05).to(DEV)
@@ -251,7 +251,7 @@ def test_matmul_mfma256_path(case, monkeypatch):
     dict(M=1024, N=4096, K=1024, dt=torch.bfloat16, cs=True),            # split-K over f32 partials
     dict(M=768, N=4000, K=2048, dt=torch.float16, qt="fp4"),             # split-K, ragged N
     dict(M=700, N=3800, K=1088, dt=torch.bfloat16, cd=torch.float32),    # split-K with a short last slice, f32 output
-    dict(M=384, N=4096, K=4096, dt=torch.bfloat16),                      # 256 x 128 tiles, 48 of them: split-K
+    dict(M=640, N=4096, K=4096, dt=torch.bfloat16),                      # 128 x 128 tiles, 160 of them (512 rows and fewer: k_gemm_small, round 3)
     dict(M=257, N=11008, K=512, dt=torch.float16, cs=True),              # 256 x 128 tiles, ragged M (one row in the third tile)
     dict(M=512, N=2048, K=8192, dt=torch.bfloat16),                      # few tiles, long K: the plan still splits K (round 3)
 ])
@@ -398,12 +398,14 @@ def test_matmul_row_independence_and_linearity_full_size():
     Yh = bnb.matmul_4bit(X * 0.5, packed, st)
     big = Y.abs() > 1e-2
     assert torch.equal((Yh * 2)[big], Y[big])
-    # the same rows through the other kernels: GEMV (1 row), skinny MFMA (4, 24 rows), k_gemm_small (150, 240), decode once on 128 x 128 tiles (500)
-    for rows_n, kern in ((1, "gemv"), (4, "skinny_mfma16"), (24, "skinny_mfma16"), (150, "mfma_small_splitk"), (240, "mfma_small_splitk"), (500, "dequant+dense")):
+    # the same rows through the other kernels: GEMV (1 row), skinny MFMA (4, 24 rows), k_gemm_small (150, 240; 500 rows: 16 steps of
+    # weights in registers, one K slice, round 3), decode once on 128 x 128 tiles (700)
+    for rows_n, kern in ((1, "gemv"), (4, "skinny_mfma16"), (24, "skinny_mfma16"), (150, "mfma_small_splitk"), (240, "mfma_small_splitk"), (500, "mfma_small"),
+                         (700, "dequant+dense")):
         yg = bnb.matmul_4bit(X[:rows_n], packed, st)
         assert _native.last_kernel() == kern
         assert rel_fro(yg, Y[:rows_n]) <= TOL[torch.float16]
-        if rows_n == 500:   # 128 x 128 tiles, unsplit (round 3): a row's summation order is that of the 256 x 256 tiles -> the same bits
+        if rows_n == 700:   # 128 x 128 tiles, unsplit (round 3): a row's summation order is that of the 256 x 256 tiles -> the same bits
             assert torch.equal(yg, Y[:rows_n])
 
 
@@ -870,7 +872,7 @@ def test_matmul_4bit_randomized_sweep_round2_kernels():
         cd = None if rng.random() < 0.7 else [torch.float16, torch.bfloat16, torch.float32][int(rng.integers(0, 3))]
         kern = _oracle_vs_gpu_matmul(M, N, K, dt, qt=qt, bs=bs, cs=cs, bias=bias, cd=cd, seed=5000 + case)
         seen[kern] = seen.get(kern, 0) + 1
-    assert {"mfma_small_splitk", "dequant+dense"} <= set(seen), seen     # (split-K of the dense path: test_matmul_decode_once_path, test_gemm_dense_c_entry_point)
+    assert {"mfma_small_splitk", "mfma_small", "dequant+dense"} <= set(seen), seen     # (split-K of the dense path: test_matmul_decode_once_path, test_gemm_dense_c_entry_point)
 
 
 def test_linear_int8_randomized_dispatch_sweep():
@@ -1321,3 +1323,26 @@ def test_matmul_decode_beside_equals_the_two_launch_path(M, N, K, dt, qt, dq, wi
         assert _native.last_kernel() == "decode_beside+gated"
         assert torch.equal(y, y_ref)
     assert bnb.functional.in_launch_errors() == 0
+
+
+@pytest.mark.parametrize("M,N,K,dt,qt,dq,with_bias,kern", [(512, 4096, 4096, torch.bfloat16, "nf4", False, False, "mfma_small"),
+                                                           (450, 4096, 4096, torch.float16, "fp4", True, True, "mfma_small"),
+                                                           (300, 1000, 3072, torch.bfloat16, "nf4", False, True, "mfma_small_splitk"),
+                                                           (512, 2048, 4096, torch.bfloat16, "nf4", True, False, "mfma_small_splitk"),
+                                                           (400, 5120, 4096, torch.bfloat16, "nf4", False, False, "dequant+dense"),
+                                                           (512, 4096, 8192, torch.bfloat16, "nf4", False, False, "dequant+dense_splitk")])
+def test_matmul_257_to_512_rows_stay_fused_where_one_round_serves_them(M, N, K, dt, qt, dq, with_bias, kern):
+    """Round 3: 256 < M <= 512 rows go to k_gemm_small (16 steps of weights in registers: K = 4096 in one slice) where its workgroups
+    fit the chip in one round -- 512 x 4096^2 35.6 us against 40.6 for dequantise + dense (profiles/r03_small16_ab.txt) -- and to the
+    decode-once path where they do not (more than 256 workgroups, or K beyond 16 steps per slice).  Every row against the oracle."""
+    W = synthetic.normal((N, K), dt, seed=441, std=0.05 if dq else 1.0)
+    x = synthetic.normal((M, K), dt, seed=442)
+    bias = synthetic.normal((N,), dt, seed=443) if with_bias else None
+    packed, st = bnb.quantize_4bit(W.to(DEV), blocksize=64, quant_type=qt, compress_statistics=dq)
+    y = bnb.matmul_4bit(x.to(DEV), packed, st, None if bias is None else bias.to(DEV))
+    assert _native.last_kernel() == kern
+    op, oa, os2 = oracle.quantize_4bit(W, 64, qt, dq)
+    assert torch.equal(packed.cpu(), op)
+    rows = torch.tensor(sorted(set([0, 1, 127, 128, 255, 256, 257, M - 1] + [int(v) for v in synthetic.uniform_u64(24, 77) % np.uint64(M)])))
+    ref = oracle.matmul_4bit(x[rows], op, oa, (N, K), 64, qt, dt, bias, None, os2)
+    assert rel_fro(y.cpu()[rows], ref) <= TOL[dt]
