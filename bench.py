@@ -688,7 +688,12 @@ def measure(args, wl, ctx):
                 sr, er = row_shard(M_global, r, world)
                 xs.append(gen_normal(synthetic, (er - sr, K), dt, 4321 + r, 1.0, dev))
             ref = bnb.matmul_4bit(torch.cat(xs), packed, state)
-            ok = bool(torch.equal(full, ref)) and bool(torch.equal(chunked_full.reshape(M_global, N), ref))
+            ok = bool(torch.equal(full, ref))
+            ch = chunked_full.reshape(M_global, N)
+            if M // max(1, args.chunks) > 512:      # an unsplit dense product: a row's bits do not depend on the rows computed with it
+                ok = ok and bool(torch.equal(ch, ref))
+            else:                                    # <= 512 rows per chunk may take k_gemm_small (another summation order)
+                ok = ok and float((ch.double() - ref.double()).norm() / ref.double().norm()) <= 1e-3
             del xs, ref
         out["verified"] = ok
         del full

@@ -23,8 +23,9 @@ SmallPlan gemm_small_plan(int64_t M, int64_t N, int64_t K, int maxs_mf8 = 16) {
     const int64_t mf = M > 64 ? 8 : 4, mt = (M + 16 * mf - 1) / (16 * mf), steps = K / 256;
     SmallPlan best{1, 1};
     double best_t = 1e30;
-    for (int nf = 1; nf <= 1; nf++) {   // nf = 2 (128 weight rows per workgroup) measured slower on every shape of small_check.py
-        const int64_t wgs = ((N + 64 * nf - 1) / (64 * nf)) * mt, maxs = nf == 1 ? (mf == 8 ? maxs_mf8 : 8) : 4;   // 16: k_gemm_small<.., MAXS_ = 16>
+    for (int nf = 1; nf <= 1; nf++) {   // nf = 2 (128 weight rows per workgroup) measured slower on every shape: small_check.py in round 2 (M <= 256), and
+                                        // again in round 3 above 256 rows (512 x 4096 x 2048: 29.8 us against 19.2; a step of 128 MFMAs per wave takes 3.4 us)
+        const int64_t wgs = ((N + 64 * nf - 1) / (64 * nf)) * mt, maxs = nf == 1 ? (mf == 8 ? maxs_mf8 : 8) : 8;   // 16: k_gemm_small<.., MAXS_ = 16>
         const double step_us = 0.4 * nf + (double)(mf * 8) / 55.0;     // KiB of activations per step = 16 mf x 512 / 1024 = 8 mf
         for (int64_t s = 1; s <= 16 && s <= steps; s++) {
             const int64_t per = (steps + s - 1) / s;
@@ -51,7 +52,7 @@ int64_t gemm_small_slices(int64_t M, int64_t N, int64_t K) { return gemm_small_p
 bool gemm_small_one_round(int64_t M, int64_t N, int64_t K, int64_t K_weight, int64_t ws_bytes) {
     if (M <= 256 || !gemm_small_shape(M, N, K, K_weight)) return false;
     const SmallPlan plan = gemm_small_plan(M, N, K);
-    const int64_t wgs = ((N + 63) / 64) * ((M + 127) / 128) * plan.slices;
+    const int64_t wgs = ((N + 64 * plan.nf - 1) / (64 * plan.nf)) * ((M + 127) / 128) * plan.slices;
     return wgs <= 256 && (plan.slices == 1 || ws_bytes >= plan.slices * M * N * 4);
 }
 int64_t gemm_small8_slices(int64_t M, int64_t N, int64_t K) { return gemm_small_plan(M, N, K, 8).slices; }
@@ -101,10 +102,8 @@ int launch_gemm_small(const T *x, const uint8_t *packed, const AbsmaxView &am, c
     }
 #define MBNB_SMALL(MF, NF) return launch_gemm_small_mf<T, OutT, NESTED, MF, NF>(x, packed, am, bias, out, M, N, K, K_weight, qt, bs_shift, ws, ws_bytes, plan.slices, st)
     if (M <= 64) {
-        if (plan.nf == 2) MBNB_SMALL(4, 2);
         MBNB_SMALL(4, 1);
     }
-    if (plan.nf == 2) MBNB_SMALL(8, 2);
     if ((K / 256 + plan.slices - 1) / plan.slices > 8)
         return launch_gemm_small_mf<T, OutT, NESTED, 8, 1, 16>(x, packed, am, bias, out, M, N, K, K_weight, qt, bs_shift, ws, ws_bytes, plan.slices, st);
     MBNB_SMALL(8, 1);
