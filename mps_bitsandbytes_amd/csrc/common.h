@@ -234,6 +234,14 @@ __device__ __forceinline__ float wave_sum(float v) {
 // Internal status of the per-path launchers ("this path does not serve the call, try the next one").  Never crosses the C ABI,
 // and cannot collide with a hipError_t (> 0; hipErrorInvalidValue == 1) or an MBNB_ERR_* code (-1 .. -3).
 constexpr int MBNB_NOT_APPLICABLE = -1000;
+
+// LDS-DMA issue in the pipelined GEMMs (gemm_dense.h, gemm_dense128.h, gemm_i8_inplace.h, gemm_small.h, gemm_small8.h).  1 (default): four
+// pieces share ONE M0 write -- the instruction's 12-bit offset is added to the LDS address and to the global address alike, so piece
+// 4 g + m goes out with offset 1024 m from a per-lane offset that is 1024 m smaller (tools/exp/ab_m0.py: same bits; k_gemm_dense 93.4 ->
+// 92.7 us at 4096^3).  0 (diagnostic builds): one s_mov m0 + s_nop per piece.
+#ifndef GD_M0_GROUP
+#define GD_M0_GROUP 1
+#endif
 void set_error(const char *fmt, ...);
 void set_kernel_name(const char *name);
 int check_launch(const char *what);

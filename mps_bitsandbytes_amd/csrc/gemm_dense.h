@@ -143,6 +143,14 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, 
         const int row = 8 * (FM * wave + pl) + (lane >> 3);
         voff_a[pl] = (int)(row * K * 2) + 16 * ((lane & 7) ^ ((row >> 1) & 7));
     }
+#if GD_M0_GROUP
+    // Pieces 4 g .. 4 g + 3 of an operand share ONE M0 value: the instruction's 12-bit offset is added to the LDS address and to the
+    // global address alike, so piece 4 g + m is issued with offset 1024 m from a per-lane offset that is 1024 m smaller.
+#pragma unroll
+    for (int pl = 0; pl < 8; pl++) voff_b[pl] -= (pl & 3) * 1024;
+#pragma unroll
+    for (int pl = 0; pl < FM; pl++) voff_a[pl] -= (pl & 3) * 1024;
+#endif
     const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)smem;
     // The wave-uniform operands of the DMA travel in a DmaCtx made INSIDE the loop copy that uses them: defined there by
     // readfirstlane they are SGPRs for certain (across the per-wave branch the compiler otherwise re-derives them in
@@ -165,7 +173,16 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, 
         const uint32_t dst = (q < FM ? c.lwa : c.lwb) + (uint32_t)(stage * P_IMG + pl * 1024);
         const int vo = (q < FM) ? voff_a[pl] : voff_b[pl];
         const i32x4_t rs = (q < FM) ? c.ra : c.rb;
+#if GD_M0_GROUP
+        if constexpr ((pl & 3) != 0) {
+            asm volatile("buffer_load_dwordx4 %0, %1, %2 offen offset:%3 lds" ::"v"(vo), "s"(rs), "s"(kb), "n"((pl & 3) * 1024) : "memory", "m0");
+        } else {
+            const uint32_t dstg = (q < FM ? c.lwa : c.lwb) + (uint32_t)(stage * P_IMG + pl * 1024);
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dstg), "v"(vo), "s"(rs), "s"(kb) : "memory", "m0");
+        }
+#else
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(vo), "s"(rs), "s"(kb) : "memory", "m0");
+#endif
     };
 
     // ---- fragment reads (16 x 16 x 32): lane l = row l & 15 of the fragment's 16, k chunk 4 ks + (l >> 4), swizzled by the row

@@ -68,8 +68,8 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense128(const T *__restrict__ 
     for (int pl = 0; pl < 4; pl++) {
         const int row = 8 * (4 * wave + pl) + (lane >> 3);
         const int sw = 16 * ((lane & 7) ^ ((row >> 1) & 7));
-        voff_a[pl] = (int)(row * K * 2) + sw;
-        voff_b[pl] = (int)(row * ldw * 2) + sw;
+        voff_a[pl] = (int)(row * K * 2) + sw - GD_M0_GROUP * pl * 1024;       // the piece's 1024 pl travel in the instruction offset (issue_piece)
+        voff_b[pl] = (int)(row * ldw * 2) + sw - GD_M0_GROUP * pl * 1024;
     }
     const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)smem;
     struct DmaCtx { i32x4_t ra, rb; uint32_t lw; };
@@ -89,7 +89,10 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense128(const T *__restrict__ 
         const uint32_t dst = c.lw + (uint32_t)(stage * G128_STAGE + (q < 4 ? 0 : 16384) + pl * 1024);
         const int vo = (q < 4) ? voff_a[pl] : voff_b[pl];
         const i32x4_t rs = (q < 4) ? c.ra : c.rb;
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(vo), "s"(rs), "s"(kb) : "memory", "m0");
+        // the operand's four pieces share ONE M0 write: the instruction offset (added to the LDS address and to the global address alike)
+        // carries the piece, the per-lane offsets are 1024 pl smaller (gemm_dense.h, GD_M0_GROUP)
+        if constexpr (GD_M0_GROUP && pl != 0) asm volatile("buffer_load_dwordx4 %0, %1, %2 offen offset:%3 lds" ::"v"(vo), "s"(rs), "s"(kb), "n"(pl * 1024) : "memory", "m0");
+        else asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(vo), "s"(rs), "s"(kb) : "memory", "m0");
     };
 
     // ---- fragment reads: lane l = row l & 15 of the fragment's 16, k chunk 4 ks + (l >> 4), swizzled by the row

@@ -76,10 +76,10 @@ __global__ __launch_bounds__(256, 1) void k_gemm_i8_inplace(const int8_t *__rest
 #pragma unroll
     for (int pl = 0; pl < 8; pl++) {
         const int row = 8 * (8 * wave + pl) + (lane >> 3);
-        voff_a[pl] = (int)(row * K) + 16 * ((lane & 7) ^ ((row >> 1) & 7));
+        voff_a[pl] = (int)(row * K) + 16 * ((lane & 7) ^ ((row >> 1) & 7)) - GD_M0_GROUP * (pl & 3) * 1024;
         const int krow = 32 * wave + 4 * pl + (lane >> 4);
         const int c = (lane & 15) ^ (((krow & 7) << 1) | ((krow >> 4) & 1));
-        voff_b[pl] = (int)(krow * N) + 16 * c;
+        voff_b[pl] = (int)(krow * N) + 16 * c - GD_M0_GROUP * (pl & 3) * 1024;
     }
     const int kstep_b = (int)(128 * N);     // bytes of B between two k-steps
     const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)smem;
@@ -102,7 +102,10 @@ __global__ __launch_bounds__(256, 1) void k_gemm_i8_inplace(const int8_t *__rest
         const int vo = (q < 8) ? voff_a[pl] : voff_b[pl];
         const i32x4_t rs = (q < 8) ? c.ra : c.rb;
         const int soff = (q < 8) ? (t << 7) : t * c.ksb;
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(vo), "s"(rs), "s"(soff) : "memory", "m0");
+        // four pieces share ONE M0 write: the instruction offset (added to the LDS address and to the global address alike) carries the
+        // piece inside the group, the per-lane offsets are that much smaller (gemm_dense.h, GD_M0_GROUP; launcher: K >= 256, N >= 256)
+        if constexpr (GD_M0_GROUP && (pl & 3) != 0) asm volatile("buffer_load_dwordx4 %0, %1, %2 offen offset:%3 lds" ::"v"(vo), "s"(rs), "s"(soff), "n"((pl & 3) * 1024) : "memory", "m0");
+        else asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(vo), "s"(rs), "s"(soff) : "memory", "m0");
     };
 
     // ---- fragment loads.  Activations (second MFMA operand): lane l = row l & 15, k chunk 4 ks + (l >> 4) of the 128-byte row.

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_small(const T *__restrict__ X, 
 #pragma unroll
     for (int i = 0; i < NPW; i++) {
         const int row = 2 * (NPW * wave + i) + (lane >> 5), pos = lane & 31;
-        voff[i] = (int)(row * K * 2) + 16 * ((pos & 16) | ((pos & 15) ^ swz(row & 15)));
+        voff[i] = (int)(row * K * 2) + 16 * ((pos & 16) | ((pos & 15) ^ swz(row & 15))) - GD_M0_GROUP * (i & 3) * 1024;
     }
     const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)smem;
     const uint32_t lds_wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(smem_base + (uint32_t)(wave * NPW * 1024)));
@@ -96,7 +96,10 @@ __global__ __launch_bounds__(256, 1) void k_gemm_small(const T *__restrict__ X, 
         const uint32_t dst = lds_wave + (uint32_t)(stage * STAGE + i * 1024);
         const int vo = voff[i];
         const i32x4_t rs = rs_a;
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(vo), "s"(rs), "s"(soff) : "memory", "m0");
+        // four pieces share ONE M0 write: the instruction offset (added to the LDS address and to the global address alike) carries the
+        // piece inside the group, the per-lane offsets are that much smaller (gemm_dense.h, GD_M0_GROUP; K >= 512 here)
+        if constexpr (GD_M0_GROUP && (i & 3) != 0) asm volatile("buffer_load_dwordx4 %0, %1, %2 offen offset:%3 lds" ::"v"(vo), "s"(rs), "s"(soff), "n"((i & 3) * 1024) : "memory", "m0");
+        else asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(vo), "s"(rs), "s"(soff) : "memory", "m0");
     };
     auto issue_a = [&](int stage, int step) __attribute__((always_inline)) {
         const int soff = __builtin_amdgcn_readfirstlane(step << 9);    // 256 k x 2 B (uniform; pinned in an SGPR for the "s" operand)
