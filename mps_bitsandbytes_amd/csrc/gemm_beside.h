@@ -45,12 +45,13 @@ constexpr int64_t gb_sync_bytes(int64_t tiles_n) { return (tiles_n * GB_COL_WORD
 template <typename T, bool NESTED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(32))) void k_decode_beside(
     const uint8_t *__restrict__ packed, AbsmaxView am, int qt, T *__restrict__ Wd, uint32_t *__restrict__ sync, int64_t N, int64_t K,
-    int64_t K_weight, int u_begin, int u_end) {        // slabs [u_begin, u_end) of the K / 512
+    int64_t K_weight, int u_begin, int u_end, uint32_t go_value) {        // slabs [u_begin, u_end) of the K / 512; go_value: see k_gemm_gated
     __shared__ __attribute__((aligned(2048))) float s_lut2[512];   // byte table: entry b = (code[b & 15], code[b >> 4])
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pr = lane >> 4, pp = lane & 15;
+    if (tid == 0 && go_value != 0u) __hip_atomic_store(sync + ((N + 255) >> 8) * GB_COL_WORDS + 1, go_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 #pragma unroll
     for (int h = 0; h < 2; h++) {
         const int e = tid * 2 + h, b = e >> 1, nib = (e & 1) ? (b >> 4) : (b & 15);
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(32))) void k_de
 template <typename T, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void k_gemm_gated(const T *__restrict__ X, const T *__restrict__ Wd, uint32_t *__restrict__ sync,
                                                        const T *__restrict__ bias, void *__restrict__ out_v, int out_dtype, int64_t M,
-                                                       int64_t N, int64_t K, int64_t ldw) {
+                                                       int64_t N, int64_t K, int64_t ldw, uint32_t go_value) {
     using Frag = typename Mfma16<T>::frag;
     using Plan = GdPlan<8>;
     constexpr int FM = 8, TM = 256, PM = 4, PN = 8;
@@ -165,6 +166,11 @@ __global__ __launch_bounds__(256, 1) void k_gemm_gated(const T *__restrict__ X, 
     const int64_t m0 = tm * TM, n0 = tn << 8;
     const int nk = (int)(K >> 6);
     const int nslab = nk / GB_SLAB;
+    // go_value != 0: the decoder sits on another stream behind hipStreamWaitValue32(go == go_value).  This launch is in the caller's
+    // stream, so its first instruction runs behind everything the decoder must wait for (the previous user of the scratch, whatever
+    // produced the packed weight): every workgroup publishes the word, the command processor starts the decoder ~1.2 us later
+    // (profiles/r03_waitvalue_probe.txt; an event between the two queues costs 7-10 us).
+    if (tid == 0 && go_value != 0u) __hip_atomic_store(sync + tiles_n * GB_COL_WORDS + 1, go_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 #ifdef GB_STAMPS
     uint64_t *stamp = reinterpret_cast<uint64_t *>(sync) + 2048 + 4096 + 4 * blockIdx.x;
     if (tid == 0) stamp[0] = wall_clock64();
@@ -375,6 +381,8 @@ __global__ __launch_bounds__(256, 1) void k_gemm_gated(const T *__restrict__ X, 
         const uint32_t prev = atomicAdd(col_sync + 64, 1u);
         if (prev == (uint32_t)tiles_m - 1) {
             for (int u = 0; u < nslab; u++) __hip_atomic_store(col_sync + u, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // the epoch word too (WaitValue arrangement): the decoder was launched long ago; the area is all zero again after the call
+            __hip_atomic_store(sync + tiles_n * GB_COL_WORDS + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(col_sync + 64, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }

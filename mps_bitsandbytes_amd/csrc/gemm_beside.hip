@@ -60,13 +60,13 @@ static int launch_beside(const void *A, int64_t M, int64_t K, const uint8_t *pac
         // ordinary launch again and waits for both.
         if (am.i8 != nullptr)
             hipLaunchKernelGGL((k_decode_beside<T, true>), dim3(dgrid), dim3(256), GB_DEC_LDS, st, packed, am, qt, static_cast<T *>(ws),
-                               static_cast<uint32_t *>(sync), N, K, K_weight, 0, nslab);
+                               static_cast<uint32_t *>(sync), N, K, K_weight, 0, nslab, 0u);
         else
             hipLaunchKernelGGL((k_decode_beside<T, false>), dim3(dgrid), dim3(256), GB_DEC_LDS, st, packed, am, qt, static_cast<T *>(ws),
-                               static_cast<uint32_t *>(sync), N, K, K_weight, 0, nslab);
+                               static_cast<uint32_t *>(sync), N, K, K_weight, 0, nslab, 0u);
         if (int rc = check_launch("matmul_4bit(beside decoder)")) return rc;
         hipExtLaunchKernelGGL(kg, dim3((unsigned)tiles), dim3(256), GD_LDS, st, nullptr, nullptr, hipExtAnyOrderLaunch, static_cast<const T *>(A),
-                              static_cast<const T *>(ws), static_cast<uint32_t *>(sync), static_cast<const T *>(bias), out, out_dtype, M, N, K, K_weight);
+                              static_cast<const T *>(ws), static_cast<uint32_t *>(sync), static_cast<const T *>(bias), out, out_dtype, M, N, K, K_weight, 0u);
         return check_launch("matmul_4bit(beside)");
     }
     std::lock_guard<std::mutex> lk(g_beside_mu);
@@ -75,10 +75,10 @@ static int launch_beside(const void *A, int64_t M, int64_t K, const uint8_t *pac
     auto decode_range = [&](hipStream_t s, int u0, int u1) {
         if (am.i8 != nullptr)
             hipLaunchKernelGGL((k_decode_beside<T, true>), dim3(dgrid), dim3(256), GB_DEC_LDS, s, packed, am, qt, static_cast<T *>(ws),
-                               static_cast<uint32_t *>(sync), N, K, K_weight, u0, u1);
+                               static_cast<uint32_t *>(sync), N, K, K_weight, u0, u1, 0u);
         else
             hipLaunchKernelGGL((k_decode_beside<T, false>), dim3(dgrid), dim3(256), GB_DEC_LDS, s, packed, am, qt, static_cast<T *>(ws),
-                               static_cast<uint32_t *>(sync), N, K, K_weight, u0, u1);
+                               static_cast<uint32_t *>(sync), N, K, K_weight, u0, u1, 0u);
     };
     if (order & 4) {
         // SPLIT: a dependency between two queues costs ~8 us on this platform (profiles/r03_beside_timeline.txt), so the slabs the
@@ -94,7 +94,7 @@ static int launch_beside(const void *A, int64_t M, int64_t K, const uint8_t *pac
         }
         decode_range(st, 0, head);
         hipLaunchKernelGGL(kg, dim3((unsigned)tiles), dim3(256), GD_LDS, st, static_cast<const T *>(A), static_cast<const T *>(ws),
-                           static_cast<uint32_t *>(sync), static_cast<const T *>(bias), out, out_dtype, M, N, K, K_weight);
+                           static_cast<uint32_t *>(sync), static_cast<const T *>(bias), out, out_dtype, M, N, K, K_weight, 0u);
         int rc = check_launch("matmul_4bit(beside split)");
         // No join outside a capture: the GEMM cannot finish before it has seen the flag of the decoder's last slab, i.e. before the
         // decoder's last store has left, and whatever follows in the caller's stream follows the GEMM.  (A capture needs the side
@@ -108,7 +108,7 @@ static int launch_beside(const void *A, int64_t M, int64_t K, const uint8_t *pac
     auto decode = [&]() { decode_range(c->side, 0, nslab); };
     auto gemm = [&]() {
         hipLaunchKernelGGL(kg, dim3((unsigned)tiles), dim3(256), GD_LDS, st, static_cast<const T *>(A), static_cast<const T *>(ws),
-                           static_cast<uint32_t *>(sync), static_cast<const T *>(bias), out, out_dtype, M, N, K, K_weight);
+                           static_cast<uint32_t *>(sync), static_cast<const T *>(bias), out, out_dtype, M, N, K, K_weight, 0u);
     };
     if (order == 0) { decode(); gemm(); } else { gemm(); decode(); }
     int rc = check_launch("matmul_4bit(beside)");

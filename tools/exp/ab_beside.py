@@ -73,6 +73,6 @@ if len(sys.argv) > 1 and sys.argv[1] == "time":
                 res[k].append(ev(f, 200))
         for k, v in res.items():
             v = sorted(v)
-            print(f"{M} x {N} x {K}{' dq' if dq else ''}: {k:40s} median {v[3]:7.2f} us  min {v[0]:7.2f}  max {v[-1]:7.2f}", flush=True)
+            print(f"{M} x {N} x {K}{' dq' if dq else ''}: {k:44s} median {v[3]:7.2f} us  min {v[0]:7.2f}  max {v[-1]:7.2f}", flush=True)
     F.DECODE_BESIDE = False; F.BESIDE_GEMM_FIRST = False; F.BESIDE_SPLIT = False
     print("sync words set:", F.in_launch_errors(), flush=True)

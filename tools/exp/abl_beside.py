@@ -57,6 +57,7 @@ legs = {
     "two streams, decoder first": lambda: run(4, 0),
     "two streams, GEMM first": lambda: run(5, 0),
     "two streams, GEMM first, UNgated": lambda: (run(5, 7), zero()),
+    "WaitValue": lambda: run(6, 0),
     "gated alone, polls, no waits": lambda: run(1, 3),
     "gated alone, no polls": lambda: run(1, 7),
     "decoder + UNgated any-order": lambda: (run(0, 7), zero()),
@@ -130,3 +131,15 @@ def timeline(mode, label):
 timeline(0, "one stream, any-order")
 timeline(4, "two streams, decoder first")
 timeline(5, "two streams, GEMM first")
+timeline(6, "WaitValue")
+import time
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(200):
+    run(6, 0)
+t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+print(f"host time per WaitValue call (3 API calls): {(t1 - t0) / 200 * 1e6:.1f} us enqueue, {(t2 - t0) / 200 * 1e6:.1f} us incl. drain")
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(200):
+    run(3, 0)
+t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+print(f"host time per ordered call (2 launches): {(t1 - t0) / 200 * 1e6:.1f} us enqueue, {(t2 - t0) / 200 * 1e6:.1f} us incl. drain")
