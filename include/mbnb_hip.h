@@ -16,10 +16,19 @@
  *     arguments) and reads no environment variables.  The only process-wide state is a
  *     mutex-protected record of which (device, kernel) pairs already had their dynamic-LDS
  *     limit raised -- an idempotent attribute set once per device, so several devices can be
- *     driven from one process or from one process each;
+ *     driven from one process or from one process each -- and, once the side-stream forms below
+ *     have been used, that stream and its two events per device;
  *   - errors are returned as an int status (0 ok, <0 argument error,
  *     >0 hipError_t); no exception crosses the ABI.  mbnb_last_error()
- *     returns a thread-local description of the last failure.
+ *     returns a thread-local description of the last failure;
+ *   - there are NO `_cpu` variants (the reference dispatches tensors that are not on its device to
+ *     pure-PyTorch code, functional.py:710-767; SURVEY.md 8b lists `_cpu` entry points as optional):
+ *     every pointer is a device pointer and a call without a usable HIP device fails with the
+ *     hipError_t of its first launch.  The CPU restatement of the reference lives in oracle/ and
+ *     is test infrastructure only -- nothing in this library links, loads or calls it;
+ *   - two entry points may enqueue work on a LIBRARY-OWNED side stream forked from / joined to
+ *     `stream` by events: mbnb_matmul_4bit_sync with MBNB_MATMUL_SIDE_STREAM or
+ *     MBNB_MATMUL_SPLIT_DECODE (off in the Python mirror).  Everything else touches `stream` only.
  *
  * All tensors are dense, row-major, contiguous.  All pointers are DEVICE
  * pointers on the current HIP device (the caller selects the device).
