@@ -977,9 +977,44 @@ int quantize_4bit_dispatch(const void *A, int dtype, int64_t rows, int64_t cols,
     }
 }
 
+// Flat form (round 3) for the matrices the decode-once path dequantises: 16-bit outputs, no row padding (cols == cols_padded), whole
+// dwords and whole blocks per row -- the flat dword index IS the address of everything (packed dword g, block 8 g >> bs_shift, output
+// piece g), so the row / column arithmetic of k_dequantize_4bit goes away.  Same arithmetic per value -> the same bits.  4096^2: 9.05 ->
+// 8.17 us; inside the M = 1024 / 4096 steps -1.4 / -0.7 us (tools/exp/ab_dq4.py, ab_dq4_step.py, profiles/r03_dequant_flat_ab.txt; the
+// same kernel with NONTEMPORAL stores runs 6.7 us -- the rate of a plain fill -- but the GEMM that reads the scratch next then pays more than
+// the pass saved: 1024 x 4096^2 step 44.0 -> 49.8 us, so the stores stay cached).
+template <typename T, int QT, bool NESTED>
+__global__ __launch_bounds__(256) void k_dequantize_4bit_flat(const uint8_t *__restrict__ packed, AbsmaxView am, int64_t ndw, int bs_shift,
+                                                             T *__restrict__ out) {
+    __shared__ float lut[16];
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool ok = g < ndw;
+    // the packed dword and its absmax are requested before the code table is filled (its barrier sits under the HBM round trip)
+    const uint32_t w = ok ? reinterpret_cast<const uint32_t *>(packed)[g] : 0u;
+    const float a = ok ? load_absmax<NESTED>(am, (g * 8) >> bs_shift) : 0.0f;
+    fill_code_lut<QT>(lut, threadIdx.x);
+    __syncthreads();
+    if (!ok) return;
+    u32x4 p;
+#pragma unroll
+    for (int j = 0; j < 4; j++) p[j] = pack2<T>(lut[(w >> (8 * j)) & 15] * a, lut[(w >> (8 * j + 4)) & 15] * a);
+    reinterpret_cast<u32x4 *>(out)[g] = p;
+}
+
 template <typename T, int QT>
 static int launch_dequantize_4bit(const uint8_t *packed, const AbsmaxView &am, int64_t rows, int64_t cols,
                                   int64_t cols_padded, int blocksize, void *out, hipStream_t st) {
+    if constexpr (sizeof(T) == 2) {
+        const int64_t ndw = rows * cols / 8;
+        if (cols == cols_padded && cols % 8 == 0 && blocksize >= 8 && cols % blocksize == 0 && aligned16(out) &&
+            (reinterpret_cast<uintptr_t>(packed) & 3) == 0 && ndw >= 65536 && (ndw + 255) / 256 <= 0x7FFFFFFF) {
+            const dim3 grid((unsigned)((ndw + 255) / 256));
+            const int sh = __builtin_ctz((unsigned)blocksize);
+            if (am.i8) hipLaunchKernelGGL((k_dequantize_4bit_flat<T, QT, true>), grid, dim3(256), 0, st, packed, am, ndw, sh, static_cast<T *>(out));
+            else hipLaunchKernelGGL((k_dequantize_4bit_flat<T, QT, false>), grid, dim3(256), 0, st, packed, am, ndw, sh, static_cast<T *>(out));
+            return check_launch("dequantize_4bit");
+        }
+    }
     const int64_t gpr = (cols + 7) / 8;
     const int64_t groups = rows * gpr;
     const bool row_grid = gpr >= 256 && (gpr + 255) / 256 <= 65535 && rows <= 0x7FFFFFFF;
