@@ -662,7 +662,7 @@ def measure(args, wl, ctx):
             dense_us, deq_us = ev_us(dense_only), ev_us(dequant_only)
             assert torch.equal(Yd, bnb.matmul_4bit(X, packed, state)), "dense-only launch differs from the step's output"
             d_tflops = flops_per_step / (dense_us * 1e-6) / 1e12
-            out["roofline"]["launches"] = ["k_dequantize_4bit (N x K_weight 16-bit values into the scratch)", "k_gemm_dense"]
+            out["roofline"]["launches"] = ["k_dequantize_4bit_flat (N x K_weight 16-bit values into the scratch)", "k_gemm_dense"]
             out["roofline"]["dominant_kernel"] = {
                 "kernel": "k_gemm_dense", "kernel_us": round(dense_us, 2), "achieved": round(d_tflops, 2), "frac": round(d_tflops / peak, 4),
                 "traffic": traffic.get("k_gemm_dense_bytes_per_launch") if wl == "nf4_m4096" else traffic.get("nf4dq_ffn_gemm_dense_bytes_per_launch"),
