@@ -65,8 +65,14 @@ static int launch_beside(const void *A, int64_t M, int64_t K, const uint8_t *pac
             hipLaunchKernelGGL((k_decode_beside<T, false>), dim3(dgrid), dim3(256), GB_DEC_LDS, st, packed, am, qt, static_cast<T *>(ws),
                                static_cast<uint32_t *>(sync), N, K, K_weight, 0, nslab, 0u);
         if (int rc = check_launch("matmul_4bit(beside decoder)")) return rc;
-        hipExtLaunchKernelGGL(kg, dim3((unsigned)tiles), dim3(256), GD_LDS, st, nullptr, nullptr, hipExtAnyOrderLaunch, static_cast<const T *>(A),
-                              static_cast<const T *>(ws), static_cast<uint32_t *>(sync), static_cast<const T *>(bias), out, out_dtype, M, N, K, K_weight, 0u);
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cap) != hipSuccess) (void)hipGetLastError();
+        if (cap != hipStreamCaptureStatusNone)      // inside a capture: an ordinary kernel node behind the decoder's
+            hipLaunchKernelGGL(kg, dim3((unsigned)tiles), dim3(256), GD_LDS, st, static_cast<const T *>(A), static_cast<const T *>(ws),
+                               static_cast<uint32_t *>(sync), static_cast<const T *>(bias), out, out_dtype, M, N, K, K_weight, 0u);
+        else
+            hipExtLaunchKernelGGL(kg, dim3((unsigned)tiles), dim3(256), GD_LDS, st, nullptr, nullptr, hipExtAnyOrderLaunch, static_cast<const T *>(A),
+                                  static_cast<const T *>(ws), static_cast<uint32_t *>(sync), static_cast<const T *>(bias), out, out_dtype, M, N, K, K_weight, 0u);
         return check_launch("matmul_4bit(beside)");
     }
     std::lock_guard<std::mutex> lk(g_beside_mu);

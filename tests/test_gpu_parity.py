@@ -1346,3 +1346,30 @@ def test_matmul_257_to_512_rows_stay_fused_where_one_round_serves_them(M, N, K, 
     rows = torch.tensor(sorted(set([0, 1, 127, 128, 255, 256, 257, M - 1] + [int(v) for v in synthetic.uniform_u64(24, 77) % np.uint64(M)])))
     ref = oracle.matmul_4bit(x[rows], op, oa, (N, K), 64, qt, dt, bias, None, os2)
     assert rel_fro(y.cpu()[rows], ref) <= TOL[dt]
+
+
+def test_matmul_decode_beside_inside_a_graph_capture(monkeypatch):
+    """The decode-beside path captured into a HIP graph (one-stream arrangement: the gated GEMM becomes an ordinary kernel node behind the
+    decoder's; two-stream arrangement: fork / join edges) replays to the bits of the eager two-launch result."""
+    M, N, K = 4096, 2560, 2048
+    W = synthetic.normal((N, K), torch.bfloat16, seed=451)
+    x = synthetic.normal((M, K), torch.bfloat16, seed=452).to(DEV)
+    packed, st = bnb.quantize_4bit(W.to(DEV), blocksize=64, quant_type="nf4")
+    y_ref = bnb.matmul_4bit(x, packed, st)
+    for side in (False, True):
+        monkeypatch.setattr(bnb.functional, "DECODE_BESIDE", True)
+        monkeypatch.setattr(bnb.functional, "BESIDE_SIDE_STREAM", side)
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            y_warm = bnb.matmul_4bit(x, packed, st)            # sync area of this stream allocated and cleared outside the capture
+            assert _native.last_kernel() == "decode_beside+gated"
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s):
+                y = bnb.matmul_4bit(x, packed, st)
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(y, y_ref) and torch.equal(y_warm, y_ref)
+        monkeypatch.setattr(bnb.functional, "DECODE_BESIDE", False)
+    assert bnb.functional.in_launch_errors() == 0
