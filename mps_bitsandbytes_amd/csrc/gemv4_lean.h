@@ -14,8 +14,10 @@
 //   * the activations go to LDS by LDS-DMA (as k_gemv4), everything is requested before the first wait;
 //   * the wave reduction runs on DPP row shifts / broadcasts (no LDS round trips).
 // Same arithmetic per weight as k_gemv4 (table x absmax in f32, RNE to 16 bit, v_dot2 f32 accumulation; lane-order of the partial
-// sums differs in the reduction tree only).  Requirements: M = 1, blocksize 64 (plain or double-quantised absmax), K in {2048,
-// 4096, 8192}, K_weight == K, 16-bit weights, 16-byte aligned rows.
+// sums differs in the reduction tree only).  Requirements: M = 1, blocksize 64 (plain or double-quantised absmax), K % 64 == 0,
+// K <= 2048 KU (KU = 1, 2, 3, 4, 6, 8: a row whose last chunk is partial reads zeros past its end -- the descriptors' range checks --
+// and the activations past K land in LDS as zeros, by the same check), K_weight == K, 16-bit weights, 16-byte aligned rows; the
+// double-quantised form also nblk % 4 == 0 (the codes are fetched as aligned dwords).
 #pragma once
 #include "gemv4.h"
 
@@ -47,11 +49,20 @@ __global__ __launch_bounds__(256) void k_gemv4_lean(const T *__restrict__ X, con
     const int64_t nblk = K >> 6, row_bytes = K >> 1;
 
     // ---- activations -> LDS (1 KiB per wave-instruction), then every weight / absmax request of the row, then the table
+    {
+        // buffer form: bytes past the K activations read as zeros without touching memory (the row's last chunk may be partial)
+        typedef int i32x4_t __attribute__((ext_vector_type(4)));
+        const uint64_t px = reinterpret_cast<uint64_t>(X);
+        i32x4_t rs_x = i32x4_t{(int)(uint32_t)px, (int)(uint32_t)(px >> 32), (int)(K * 2), 0x00020000};
 #pragma unroll
-    for (int u = 0; u < KU; u++) {
-        auto g = (const __attribute__((address_space(1))) void *)(X + 2048 * u + tid * 8);
-        auto l = (__attribute__((address_space(3))) void *)(xs + 4096 * u + wave * 1024);
-        __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
+        for (int e = 0; e < 4; e++) rs_x[e] = __builtin_amdgcn_readfirstlane(rs_x[e]);
+        const uint32_t xs_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)xs;
+#pragma unroll
+        for (int u = 0; u < KU; u++) {
+            const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(xs_base + 4096u * u + 1024u * wave));
+            const int vo = 4096 * u + tid * 16;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(dst), "v"(vo), "s"(rs_x) : "memory", "m0");
+        }
     }
     // per-wave buffer descriptors: the row's packed bytes, its absmax (NESTED: its codes, and the absmax2 array); n is wave-uniform
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(packed + n * row_bytes), 0, (int)row_bytes, 0x00020000);
@@ -71,7 +82,7 @@ __global__ __launch_bounds__(256) void k_gemv4_lean(const T *__restrict__ X, con
         } else {
             const int bi = 32 * u + (lane >> 1);
             aq[u] = __builtin_amdgcn_raw_buffer_load_b32(rs_m, bi & ~3, 0, 0);        // the aligned dword that holds code bi
-            const int64_t gi = n * nblk + bi;
+            const int64_t gi = n * nblk + (bi < (int)nblk ? bi : (int)nblk - 1);     // blocks past the row: code 0 (range check), any valid absmax2
             a[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_m2, (int)((gi >> bs2_shift) << 2), 0, 0));
         }
     }

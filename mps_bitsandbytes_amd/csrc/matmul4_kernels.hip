@@ -304,17 +304,23 @@ static int launch_matmul4(const void *A, int64_t M, int64_t K, const uint8_t *pa
             hipLaunchKernelGGL((k_gemv4<T, OutT, QT, NESTED, MT, NR, KU, false>), grid, dim3(256), 0, st, x, packed, \
                                am, b, o, M, N, K, K_weight, sh);                                                    \
     } while (0)
-            // M = 1, blocksize 64, K = 2048 / 4096 / 8192 (round 3): k_gemv4_lean -- the same arithmetic with the per-wave fixed cost
+            // M = 1, blocksize 64, K % 64 == 0 up to 16384 (round 3): k_gemv4_lean -- the same arithmetic with the per-wave fixed cost
             // cut (480 instead of 627 instructions per wave: buffer descriptors instead of 64-bit address VALU, table from
             // constant memory, DPP reduction, no next-trip ring); bit-equal outputs, 5.25 -> 5.08 us per rotating 4096^2 layer,
             // 4.67 -> 4.24 us on a cache-resident one (profiles/r03_gemv_lean_ab.txt)
             if constexpr (std::is_same<OutT, T>::value) {
-                if (M == 1 && blocksize == 64 && K_weight == K && N < 8192 && (K == 2048 || K == 4096 || K == 8192) &&
-                    (!NESTED || (am.bs2 > 0 && (am.bs2 & (am.bs2 - 1)) == 0 && (reinterpret_cast<uintptr_t>(am.i8) & 3) == 0))) {
+                const int64_t ku = (K + 2047) / 2048;
+                if (M == 1 && blocksize == 64 && K_weight == K && K % 64 == 0 && K >= 1024 && ku <= 8 && N * (K / 2) < ((int64_t)1 << 40) &&
+                    (!NESTED || (am.bs2 > 0 && (am.bs2 & (am.bs2 - 1)) == 0 && (reinterpret_cast<uintptr_t>(am.i8) & 3) == 0 && (K / 64) % 4 == 0))) {
                     const dim3 grid((unsigned)((N + 3) / 4));
-                    if (K == 2048) hipLaunchKernelGGL((k_gemv4_lean<T, OutT, QT, NESTED, 1>), grid, dim3(256), (size_t)K * 2, st, x, packed, am, b, o, N, K);
-                    else if (K == 4096) hipLaunchKernelGGL((k_gemv4_lean<T, OutT, QT, NESTED, 2>), grid, dim3(256), (size_t)K * 2, st, x, packed, am, b, o, N, K);
-                    else hipLaunchKernelGGL((k_gemv4_lean<T, OutT, QT, NESTED, 4>), grid, dim3(256), (size_t)K * 2, st, x, packed, am, b, o, N, K);
+#define MBNB_LEAN(KU) hipLaunchKernelGGL((k_gemv4_lean<T, OutT, QT, NESTED, KU>), grid, dim3(256), (size_t)KU * 4096, st, x, packed, am, b, o, N, K)
+                    if (ku == 1) MBNB_LEAN(1);
+                    else if (ku == 2) MBNB_LEAN(2);
+                    else if (ku == 3) MBNB_LEAN(3);
+                    else if (ku == 4) MBNB_LEAN(4);
+                    else if (ku <= 6) MBNB_LEAN(6);
+                    else MBNB_LEAN(8);
+#undef MBNB_LEAN
                     set_kernel_name("gemv");
                     return check_launch("matmul_4bit(gemv lean)");
                 }

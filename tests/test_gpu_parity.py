@@ -1278,7 +1278,12 @@ def test_matmul_in_launch_decode_equals_the_two_launch_path(M, N, K, dt, qt, wit
 
 @pytest.mark.parametrize("N,K,dt,qt,dq,with_bias", [(4096, 4096, torch.bfloat16, "nf4", False, False), (4096, 4096, torch.float16, "nf4", True, True),
                                                      (1000, 2048, torch.bfloat16, "fp4", False, True), (515, 8192, torch.float16, "nf4", False, False),
-                                                     (4096, 8192, torch.bfloat16, "nf4", True, False)])
+                                                     (4096, 8192, torch.bfloat16, "nf4", True, False),
+                                                     (1030, 5120, torch.bfloat16, "nf4", False, True),       # 2.5 chunks: the last one half empty
+                                                     (777, 11008, torch.float16, "nf4", True, False),        # 5.4 chunks on the 6-chunk form, nested absmax
+                                                     (11008, 4096, torch.bfloat16, "fp4", False, False),     # N >= 8192
+                                                     (300, 14336, torch.bfloat16, "nf4", False, True),       # 7 chunks on the 8-chunk form
+                                                     (256, 1088, torch.float16, "nf4", False, False)])       # one partial chunk
 def test_matmul_m1_lean_gemv_vs_oracle(N, K, dt, qt, dq, with_bias):
     """M = 1 at K = 2048 / 4096 / 8192, blocksize 64 -> k_gemv4_lean (round 3).  VERDICT r2's thin spot: the bf16 instantiation the
     bench's `gemv` object times at 4096^2 against the oracle at that size; plus FP4, double-quantised absmax, bias, a ragged N
