@@ -35,6 +35,12 @@ template <int N, class F> __device__ __forceinline__ void gs_static_for(F &&f) {
 }
 
 template <int MF> constexpr int gemm_small_lds_bytes() { return 2 * 16 * MF * 512; }
+#ifdef GS_STAMPS
+__device__ unsigned long long g_gs_stamps[256];      // diagnostic builds (tools/exp/small_stamps.hip): cycle stamps of one wave's steps
+#ifndef GS_STAMP_TID
+#define GS_STAMP_TID 0
+#endif
+#endif
 
 // MAXS_: steps of a slice whose weights the prologue loads into registers (12 registers per step and fragment); 0 = 8 (NF = 1) / 4
 // (NF = 2).  16 (round 3): K = 4096 in ONE slice -- 384 < M <= 512 rows on a 4096-wide layer are 256 workgroups in one round with
@@ -146,15 +152,6 @@ __global__ __launch_bounds__(256, 1) void k_gemm_small(const T *__restrict__ X, 
             }
         });
     };
-    auto wait_all = [&](WRegs (&r)[MAXS]) __attribute__((always_inline)) {   // every load of the prologue has landed; the registers travel through the wait
-        gs_static_for<MAXS * NF>([&](auto q) {
-            constexpr int i = decltype(q)::value / NF, f = decltype(q)::value % NF;
-            u32x4 &w0 = r[i].w[f][0], &w1 = r[i].w[f][1];
-            uint32_t &a0 = r[i].a[f][0], &a1 = r[i].a[f][1];
-            float &b0 = r[i].a2[f][0], &b1 = r[i].a2[f][1];
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(w0), "+v"(w1), "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1)::"memory");
-        });
-    };
     auto absmax_of = [&](const WRegs &r, float (&ra)[NF][2]) __attribute__((always_inline)) {
         gs_static_for<NF * 2>([&](auto fj) {
             constexpr int f = decltype(fj)::value >> 1, j = decltype(fj)::value & 1;
@@ -174,13 +171,16 @@ __global__ __launch_bounds__(256, 1) void k_gemm_small(const T *__restrict__ X, 
 #pragma unroll
         for (int g = 0; g < MF; g++) acc[f][g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
-    // Prologue.  The slice of a workgroup is short (<= MAXS steps, the launcher's choice).  Its weights -- 32 bytes per lane,
-    // fragment and step -- are loaded into registers right away (in flight only until the first wait: a register with a load in
-    // flight must not be live across anything the compiler may turn into a copy, such as a loop back-edge).  (Touching the later
-    // steps' activation lines at this point to have them in L2 early was measured: no gain, 18.7 vs 17.4 us at 128 x 4096 x 4096.)
+    // Prologue.  Round 3: only the weights of the first TWO steps are requested up front; the request of step t + 2 goes out at the END of
+    // step t, behind that step's last LDS-DMA piece, so that the wait at the start of step t + 1 -- vmcnt(NW): everything but the newest
+    // NW operations -- leaves it in flight for a whole step; it has landed by the wait of step t + 2 (in-order counter), where the registers
+    // are passed through an empty asm before their first use.  (Until then ALL steps of the slice were requested and awaited here: 128 KiB
+    // per workgroup at 16 steps, 33.5 MB over the grid of a 512 x 4096 x 4096 call -- 10 of its 35 us went by before the first MFMA,
+    // tools/exp/small_stamps.py.)  The steps are fully unrolled, so every step's registers are their own: no ring, no copies.
+    constexpr int NW = NF * 2 * (NESTED ? 3 : 2);     // vector-memory instructions of one step's weight request
     WRegs wr[MAXS];
     issue_a(0, 0);
-    gs_static_for<MAXS>([&](auto ii) {
+    gs_static_for<2>([&](auto ii) {
         constexpr int i = decltype(ii)::value;
         if (i < nsteps) {
             load_w(i, wr[i]);
@@ -193,7 +193,18 @@ __global__ __launch_bounds__(256, 1) void k_gemm_small(const T *__restrict__ X, 
             });
         }
     });
-    wait_all(wr);
+    auto landed = [&](WRegs &r, bool wait) __attribute__((always_inline)) {    // the registers travel through the wait / past it
+        gs_static_for<NF>([&](auto ff) {
+            constexpr int f = decltype(ff)::value;
+            u32x4 &w0 = r.w[f][0], &w1 = r.w[f][1];
+            uint32_t &a0 = r.a[f][0], &a1 = r.a[f][1];
+            float &b0 = r.a2[f][0], &b1 = r.a2[f][1];
+            if (wait) asm volatile("s_waitcnt vmcnt(0)" : "+v"(w0), "+v"(w1), "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1)::"memory");
+            else asm volatile("" : "+v"(w0), "+v"(w1), "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1)::"memory");
+        });
+    };
+    landed(wr[0], true);
+    landed(wr[1], true);
 
     // One 256-k step = 8 slices (j, s) of NF x MF MFMAs.  One wave per SIMD: nothing hides an LDS round trip between a read and
     // the MFMA that uses it, so the step is software-pipelined by hand -- the MF activation fragments of slice i+1 and the
@@ -268,9 +279,34 @@ __global__ __launch_bounds__(256, 1) void k_gemm_small(const T *__restrict__ X, 
     // step t: activations in stage t & 1 (A(t+1) goes out during step t, behind the barrier that frees its stage), weights in wr[t]
     auto step = [&](auto tt) __attribute__((always_inline)) {
         constexpr int TT = decltype(tt)::value;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef GS_STAMPS
+        const uint64_t ta = __builtin_readcyclecounter();
+#endif
+        if constexpr (TT == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            // the request of step TT + 1 (issued at the end of step TT - 1, if that step exists) stays in flight
+            const int more = __builtin_amdgcn_readfirstlane(TT + 1 < nsteps ? 1 : 0);
+            asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 .Lgs_w0%=\n\ts_waitcnt vmcnt(%1)\n\ts_branch .Lgs_w1%=\n.Lgs_w0%=:\n\ts_waitcnt vmcnt(0)\n.Lgs_w1%=:"
+                         ::"s"(more), "n"(NW) : "scc", "memory");
+        }
+#ifdef GS_STAMPS
+        const uint64_t tw = __builtin_readcyclecounter();
+#endif
         __syncthreads();        // A(t) visible; every wave is done reading the other stage (step t - 1); byte table written
+#ifdef GS_STAMPS
+        const uint64_t tb = __builtin_readcyclecounter();
+#endif
+        if constexpr (TT >= 2) landed(wr[TT], false);
         compute(TT & 1, wr[TT], TT + 1 < nsteps ? TT + 1 : -1);
+        if constexpr (TT + 2 < MAXS) {
+            if (TT + 2 < nsteps) load_w(TT + 2, wr[TT + 2]);
+        }
+#ifdef GS_STAMPS
+        if (tid == GS_STAMP_TID && blockIdx.x == 7 && blockIdx.y == 0 && blockIdx.z == 0) {
+            g_gs_stamps[4 * TT + 0] = ta; g_gs_stamps[4 * TT + 1] = tw; g_gs_stamps[4 * TT + 2] = tb; g_gs_stamps[4 * TT + 3] = __builtin_readcyclecounter();
+        }
+#endif
     };
     gs_static_for<MAXS>([&](auto tt) {
         if (decltype(tt)::value < nsteps) step(tt);
