@@ -71,12 +71,12 @@ __global__ __launch_bounds__(256, 1) void k_gemm_small8(const T *__restrict__ X,
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dw) : "v"(pw) : "memory");
         });
     };
-    auto wait_all = [&](WRegs (&r)[MAXS]) __attribute__((always_inline)) {
-        gs_static_for<MAXS>([&](auto ii) {
-            constexpr int i = decltype(ii)::value;
-            u32x4 &w0 = r[i].w[0], &w1 = r[i].w[1], &w2 = r[i].w[2], &w3 = r[i].w[3];
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3)::"memory");
-        });
+    // the registers of a step's weights travel through the wait (prologue) / past it (steps 2 ..): no use can move above the point where
+    // they have landed
+    auto landed = [&](WRegs &r, bool wait) __attribute__((always_inline)) {
+        u32x4 &w0 = r.w[0], &w1 = r.w[1], &w2 = r.w[2], &w3 = r.w[3];
+        if (wait) asm volatile("s_waitcnt vmcnt(0)" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3)::"memory");
+        else asm volatile("" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3)::"memory");
     };
 
     // ---- activation fragment addresses: row 16 g + r16, chunk 8 j + 2 kc + h -> one register per (j & 1, h); g, j >> 1, stage immediates
@@ -95,7 +95,10 @@ __global__ __launch_bounds__(256, 1) void k_gemm_small8(const T *__restrict__ X,
         const int soff0 = 0;
         gs_static_for<NPW>([&](auto ii) { issue_piece(ii, 0, soff0); });
     }
-    gs_static_for<MAXS>([&](auto ii) {
+    // the weights stream in step by step as in k_gemm_small (gemm_small.h, round 3): two steps up front, the request of step t + 2 at the END
+    // of step t, left in flight by the vmcnt(NW) at the start of step t + 1
+    constexpr int NW = 4;     // vector-memory instructions of one step's weight request
+    gs_static_for<2>([&](auto ii) {
         constexpr int i = decltype(ii)::value;
         if (i < nsteps) {
             load_w(i, wr[i]);
@@ -103,7 +106,8 @@ __global__ __launch_bounds__(256, 1) void k_gemm_small8(const T *__restrict__ X,
             gs_static_for<4>([&](auto jj) { wr[i].w[decltype(jj)::value] = u32x4{0, 0, 0, 0}; });
         }
     });
-    wait_all(wr);
+    landed(wr[0], true);
+    landed(wr[1], true);
 
     auto compute = [&](int stage, const WRegs &w, int next) __attribute__((always_inline)) {
         const int nsoff = __builtin_amdgcn_readfirstlane((next < 0 ? 0 : next) << 9);
@@ -150,9 +154,19 @@ __global__ __launch_bounds__(256, 1) void k_gemm_small8(const T *__restrict__ X,
 
     auto step = [&](auto tt) __attribute__((always_inline)) {
         constexpr int TT = decltype(tt)::value;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (TT == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            const int more = __builtin_amdgcn_readfirstlane(TT + 1 < nsteps ? 1 : 0);
+            asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 .Lg8_w0%=\n\ts_waitcnt vmcnt(%1)\n\ts_branch .Lg8_w1%=\n.Lg8_w0%=:\n\ts_waitcnt vmcnt(0)\n.Lg8_w1%=:"
+                         ::"s"(more), "n"(NW) : "scc", "memory");
+        }
         __syncthreads();
+        if constexpr (TT >= 2) landed(wr[TT], false);
         compute(TT & 1, wr[TT], TT + 1 < nsteps ? TT + 1 : -1);
+        if constexpr (TT + 2 < MAXS) {
+            if (TT + 2 < nsteps) load_w(TT + 2, wr[TT + 2]);
+        }
     };
     gs_static_for<MAXS>([&](auto tt) {
         if (decltype(tt)::value < nsteps) step(tt);
