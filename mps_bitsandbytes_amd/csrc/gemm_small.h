@@ -35,6 +35,9 @@ template <int N, class F> __device__ __forceinline__ void gs_static_for(F &&f) {
 }
 
 template <int MF> constexpr int gemm_small_lds_bytes() { return 2 * 16 * MF * 512; }
+#ifndef GS_ABL
+#define GS_ABL 0     // diagnostic builds (tools/exp/small_stamps.hip): 1 no LDS-DMA pieces in the steps, 2 no decode, 4 no fragment reads (timing only)
+#endif
 #ifdef GS_STAMPS
 __device__ unsigned long long g_gs_stamps[256];      // diagnostic builds (tools/exp/small_stamps.hip): cycle stamps of one wave's steps
 #ifndef GS_STAMP_TID
@@ -171,16 +174,18 @@ __global__ __launch_bounds__(256, 1) void k_gemm_small(const T *__restrict__ X, 
 #pragma unroll
         for (int g = 0; g < MF; g++) acc[f][g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
-    // Prologue.  Round 3: only the weights of the first TWO steps are requested up front; the request of step t + 2 goes out at the END of
-    // step t, behind that step's last LDS-DMA piece, so that the wait at the start of step t + 1 -- vmcnt(NW): everything but the newest
-    // NW operations -- leaves it in flight for a whole step; it has landed by the wait of step t + 2 (in-order counter), where the registers
-    // are passed through an empty asm before their first use.  (Until then ALL steps of the slice were requested and awaited here: 128 KiB
-    // per workgroup at 16 steps, 33.5 MB over the grid of a 512 x 4096 x 4096 call -- 10 of its 35 us went by before the first MFMA,
-    // tools/exp/small_stamps.py.)  The steps are fully unrolled, so every step's registers are their own: no ring, no copies.
+    // Prologue.  Round 3: only the weights of the first THREE steps are requested up front; the request of step t + 3 goes out at the END
+    // of step t, behind that step's last LDS-DMA piece, so that the wait at the start of step t + 1 -- vmcnt(NW): everything but the
+    // newest NW operations -- leaves it in flight for a whole step; it has landed by the wait of step t + 2 (in-order counter), one step
+    // before its first use (the tail of step t + 2 looks the first two slices of step t + 3 up, below), where the registers are passed
+    // through an empty asm.  (Until then ALL steps of the slice were requested and awaited here: 128 KiB per workgroup at 16 steps, 33.5 MB
+    // over the grid of a 512 x 4096 x 4096 call -- 10 of its 35 us went by before the first MFMA, tools/exp/small_stamps.py.)  The steps
+    // are fully unrolled, so every step's registers are their own: no ring, no copies.
     constexpr int NW = NF * 2 * (NESTED ? 3 : 2);     // vector-memory instructions of one step's weight request
+    constexpr int PD = 3;
     WRegs wr[MAXS];
     issue_a(0, 0);
-    gs_static_for<2>([&](auto ii) {
+    gs_static_for<PD>([&](auto ii) {
         constexpr int i = decltype(ii)::value;
         if (i < nsteps) {
             load_w(i, wr[i]);
@@ -193,30 +198,69 @@ __global__ __launch_bounds__(256, 1) void k_gemm_small(const T *__restrict__ X, 
             });
         }
     });
-    auto landed = [&](WRegs &r, bool wait) __attribute__((always_inline)) {    // the registers travel through the wait / past it
+    auto landed = [&](WRegs &r) __attribute__((always_inline)) {    // the registers travel past the wait: no use can move above it
         gs_static_for<NF>([&](auto ff) {
             constexpr int f = decltype(ff)::value;
             u32x4 &w0 = r.w[f][0], &w1 = r.w[f][1];
             uint32_t &a0 = r.a[f][0], &a1 = r.a[f][1];
             float &b0 = r.a2[f][0], &b1 = r.a2[f][1];
-            if (wait) asm volatile("s_waitcnt vmcnt(0)" : "+v"(w0), "+v"(w1), "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1)::"memory");
-            else asm volatile("" : "+v"(w0), "+v"(w1), "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1)::"memory");
+            asm volatile("" : "+v"(w0), "+v"(w1), "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1)::"memory");
         });
     };
-    landed(wr[0], true);
-    landed(wr[1], true);
+    // everything but the newest request (step 2's, when the slice has one) has landed
+    auto wait_but_newest = [&](bool newest_in_flight) __attribute__((always_inline)) {
+        const int more = __builtin_amdgcn_readfirstlane(newest_in_flight ? 1 : 0);
+        asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 .Lgs_w0%=\n\ts_waitcnt vmcnt(%1)\n\ts_branch .Lgs_w1%=\n.Lgs_w0%=:\n\ts_waitcnt vmcnt(0)\n.Lgs_w1%=:"
+                     ::"s"(more), "n"(NW) : "scc", "memory");
+    };
 
     // One 256-k step = 8 slices (j, s) of NF x MF MFMAs.  One wave per SIMD: nothing hides an LDS round trip between a read and
-    // the MFMA that uses it, so the step is software-pipelined by hand -- the MF activation fragments of slice i+1 and the
+    // the MFMA that uses it, so the slices are software-pipelined by hand -- the MF activation fragments of slice i+1 and the
     // byte-table lookups of slice i+2 are issued before the MFMAs of slice i, the products / packing of slice i+1 follow
-    // (independent VALU work the matrix pipe runs beside).
+    // (independent VALU work the matrix pipe runs beside).  Round 3: the pipeline runs ACROSS the step boundary -- the lookups of the
+    // next step's slices 0 and 1 and the products of its slice 0 need only that step's weights (registers), so they ride in the last two
+    // slices of this step; behind the barrier only the activation fragments of slice 0 are waited for (each step used to start with
+    // lookup -> products -> fragment reads -> first MFMA in series: ~550 of its ~2800 cycles, small_stamps.py with GS_ABL = 7).
     // next >= 0: the LDS-DMA pieces of step `next` go out into the other stage from INSIDE the step, NPW / 8 per slice behind that
     // slice's MFMAs (all of them up front cost the wave ~16 x 80 issue cycles before its first MFMA: 2.4 -> 1.x us per step)
-    auto compute = [&](int stage, const WRegs &w, int next) __attribute__((always_inline)) {
+    const char *lut2 = reinterpret_cast<const char *>(s_lut2);
+    Frag wf_c[NF];                 // finished weight fragment of the coming step's slice 0
+    f32x2 lk_c[NF][4];             // table lookups of the coming step's slice 1
+    auto lookup = [&](const WRegs &w, auto ii, f32x2 (&dst)[NF][4]) __attribute__((always_inline)) {
+        constexpr int i = decltype(ii)::value, j = i >> 2, sl = i & 3;
+        gs_static_for<NF>([&](auto ff) {
+            constexpr int f = decltype(ff)::value;
+            const uint32_t wd = w.w[f][j][sl];
+#pragma unroll
+            for (int b = 0; b < 4; b++) dst[f][b] = *reinterpret_cast<const f32x2 *>(lut2 + (((wd >> (8 * b)) & 0xFFu) << 3));
+        });
+    };
+    auto finish = [&](const f32x2 (&src)[NF][4], const float (&ra)[NF][2], auto ii, Frag (&wf)[NF]) __attribute__((always_inline)) {
+        constexpr int i = decltype(ii)::value, j = i >> 2;
+        gs_static_for<NF>([&](auto ff) {
+            constexpr int f = decltype(ff)::value;
+            u32x4 o;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                float p0, p1;
+                const float l0 = src[f][b][0], l1 = src[f][b][1], sc = ra[f][j];
+                asm("v_mul_f32 %0, %1, %2" : "=v"(p0) : "v"(l0), "v"(sc));
+                asm("v_mul_f32 %0, %1, %2" : "=v"(p1) : "v"(l1), "v"(sc));
+                o[b] = pack2<T>(p0, p1);
+            }
+            wf[f] = __builtin_bit_cast(Frag, o);
+        });
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    // wnx: the next step's weights (landed a step ago); HAS_NX: that step exists in the unrolled sequence (its registers may still hold
+    // nothing when the slice ends earlier: the lookups then read the table at whatever byte values they hold and are never used)
+    auto compute = [&](int stage, const WRegs &w, const WRegs &wnx, auto has_nx, int next) __attribute__((always_inline)) {
+        constexpr bool HAS_NX = decltype(has_nx)::value;
         const int nsoff = __builtin_amdgcn_readfirstlane((next < 0 ? 0 : next) << 9);
-        float ra[NF][2];
+        float ra[NF][2], ra_n[NF][2];
         absmax_of(w, ra);
-        const char *lut2 = reinterpret_cast<const char *>(s_lut2);
+        if constexpr (HAS_NX) absmax_of(wnx, ra_n);
         Frag xf[2][MF];
         f32x2 lk[2][NF][4];
         auto issue_x = [&](auto ii, auto pp) __attribute__((always_inline)) {
@@ -224,48 +268,25 @@ __global__ __launch_bounds__(256, 1) void k_gemm_small(const T *__restrict__ X, 
 #pragma unroll
             for (int g = 0; g < MF; g++) xf[P][g] = *reinterpret_cast<const Frag *>(smem + stage * STAGE + fa[sl] + g * 16 * 512 + j * 256);
         };
-        auto issue_lk = [&](auto ii, auto pp) __attribute__((always_inline)) {
-            constexpr int i = decltype(ii)::value, P = decltype(pp)::value, j = i >> 2, sl = i & 3;
-            gs_static_for<NF>([&](auto ff) {
-                constexpr int f = decltype(ff)::value;
-                const uint32_t wd = w.w[f][j][sl];
-#pragma unroll
-                for (int b = 0; b < 4; b++) lk[P][f][b] = *reinterpret_cast<const f32x2 *>(lut2 + (((wd >> (8 * b)) & 0xFFu) << 3));
-            });
-        };
-        auto finish = [&](auto ii, auto pp, Frag (&wf)[NF]) __attribute__((always_inline)) {
-            constexpr int i = decltype(ii)::value, P = decltype(pp)::value, j = i >> 2;
-            gs_static_for<NF>([&](auto ff) {
-                constexpr int f = decltype(ff)::value;
-                u32x4 o;
-#pragma unroll
-                for (int b = 0; b < 4; b++) {
-                    float p0, p1;
-                    const float l0 = lk[P][f][b][0], l1 = lk[P][f][b][1], sc = ra[f][j];
-                    asm("v_mul_f32 %0, %1, %2" : "=v"(p0) : "v"(l0), "v"(sc));
-                    asm("v_mul_f32 %0, %1, %2" : "=v"(p1) : "v"(l1), "v"(sc));
-                    o[b] = pack2<T>(p0, p1);
-                }
-                wf[f] = __builtin_bit_cast(Frag, o);
-            });
-        };
-        using I0 = std::integral_constant<int, 0>;
-        using I1 = std::integral_constant<int, 1>;
-        issue_lk(I0{}, I0{});
         issue_x(I0{}, I0{});
-        issue_lk(I1{}, I1{});
         Frag wf[NF], wn[NF];
-        finish(I0{}, I0{}, wf);
+#pragma unroll
+        for (int f = 0; f < NF; f++) {
+            wf[f] = wf_c[f];
+#pragma unroll
+            for (int b = 0; b < 4; b++) lk[1][f][b] = lk_c[f][b];
+        }
         gs_static_for<8>([&](auto ii) {
             constexpr int i = decltype(ii)::value, P = i & 1;
-            if constexpr (i < 7) issue_x(std::integral_constant<int, (i + 1) & 7>{}, std::integral_constant<int, P ^ 1>{});
-            if constexpr (i < 7) finish(std::integral_constant<int, (i + 1) & 7>{}, std::integral_constant<int, P ^ 1>{}, wn);
-            if constexpr (i < 6) issue_lk(std::integral_constant<int, (i + 2) & 7>{}, std::integral_constant<int, P>{});
+            if constexpr (i < 7 && !(GS_ABL & 4)) issue_x(std::integral_constant<int, (i + 1) & 7>{}, std::integral_constant<int, P ^ 1>{});
+            if constexpr (i < 7 && !(GS_ABL & 2)) finish(lk[P ^ 1], ra, std::integral_constant<int, (i + 1) & 7>{}, wn);
+            if constexpr (i < 6 && !(GS_ABL & 2)) lookup(w, std::integral_constant<int, (i + 2) & 7>{}, lk[P]);
+            if constexpr (i >= 6 && HAS_NX && !(GS_ABL & 2)) lookup(wnx, std::integral_constant<int, i - 6>{}, lk[P]);      // slices 0, 1 of the next step
 #pragma unroll
             for (int f = 0; f < NF; f++)
 #pragma unroll
                 for (int g = 0; g < MF; g++) acc[f][g] = Mfma16<T>::run(wf[f], xf[P][g], acc[f][g]);
-            if (next >= 0) {
+            if (next >= 0 && !(GS_ABL & 1)) {
                 gs_static_for<NPW / 8>([&](auto pp) { issue_piece(std::integral_constant<int, i * (NPW / 8) + decltype(pp)::value>{}, stage ^ 1, nsoff); });
             }
             if constexpr (i < 7) {
@@ -274,6 +295,13 @@ __global__ __launch_bounds__(256, 1) void k_gemm_small(const T *__restrict__ X, 
             }
             __builtin_amdgcn_sched_barrier(0);
         });
+        if constexpr (HAS_NX) {
+            finish(lk[0], ra_n, I0{}, wf_c);
+#pragma unroll
+            for (int f = 0; f < NF; f++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) lk_c[f][b] = lk[1][f][b];
+        }
     };
 
     // step t: activations in stage t & 1 (A(t+1) goes out during step t, behind the barrier that frees its stage), weights in wr[t]
@@ -282,25 +310,33 @@ __global__ __launch_bounds__(256, 1) void k_gemm_small(const T *__restrict__ X, 
 #ifdef GS_STAMPS
         const uint64_t ta = __builtin_readcyclecounter();
 #endif
-        if constexpr (TT == 0) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else {
-            // the request of step TT + 1 (issued at the end of step TT - 1, if that step exists) stays in flight
-            const int more = __builtin_amdgcn_readfirstlane(TT + 1 < nsteps ? 1 : 0);
-            asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 .Lgs_w0%=\n\ts_waitcnt vmcnt(%1)\n\ts_branch .Lgs_w1%=\n.Lgs_w0%=:\n\ts_waitcnt vmcnt(0)\n.Lgs_w1%=:"
-                         ::"s"(more), "n"(NW) : "scc", "memory");
-        }
+        // the newest weight request -- step TT + 2's, issued at the end of step TT - 1 (step 2's by the prologue) -- stays in flight
+        wait_but_newest(TT + 2 < nsteps);
 #ifdef GS_STAMPS
         const uint64_t tw = __builtin_readcyclecounter();
 #endif
-        __syncthreads();        // A(t) visible; every wave is done reading the other stage (step t - 1); byte table written
+        if constexpr (TT == 0) {
+            // the first step's slices 0 and 1 enter the pipeline here (the byte table is visible behind this barrier)
+            landed(wr[0]);
+            landed(wr[1]);
+            __syncthreads();
+            float ra0[NF][2];
+            absmax_of(wr[0], ra0);
+            f32x2 l0[NF][4];
+            lookup(wr[0], I0{}, l0);
+            lookup(wr[0], I1{}, lk_c);
+            finish(l0, ra0, I0{}, wf_c);
+        } else {
+            __syncthreads();        // A(t) visible; every wave is done reading the other stage (step t - 1)
+            if constexpr (TT + 1 < MAXS) landed(wr[TT + 1]);
+        }
 #ifdef GS_STAMPS
         const uint64_t tb = __builtin_readcyclecounter();
 #endif
-        if constexpr (TT >= 2) landed(wr[TT], false);
-        compute(TT & 1, wr[TT], TT + 1 < nsteps ? TT + 1 : -1);
-        if constexpr (TT + 2 < MAXS) {
-            if (TT + 2 < nsteps) load_w(TT + 2, wr[TT + 2]);
+        constexpr int NX = TT + 1 < MAXS ? TT + 1 : TT;
+        compute(TT & 1, wr[TT], wr[NX], std::integral_constant<bool, (TT + 1 < MAXS)>{}, TT + 1 < nsteps ? TT + 1 : -1);
+        if constexpr (TT + PD < MAXS) {
+            if (TT + PD < nsteps) load_w(TT + PD, wr[TT + PD]);
         }
 #ifdef GS_STAMPS
         if (tid == GS_STAMP_TID && blockIdx.x == 7 && blockIdx.y == 0 && blockIdx.z == 0) {

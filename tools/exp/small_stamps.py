@@ -5,7 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import torch
 import mps_bitsandbytes_amd as bnb
 dev = torch.device("cuda:0")
-lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libsmall_stamps.so"))
+abl = sys.argv[1] if len(sys.argv) > 1 else ""
+lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), f"libsmall_stamps{abl}.so"))
 lib.exp_small_stamps.restype = ctypes.c_int
 lib.exp_small_stamps.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int64] * 3 + [ctypes.c_void_p, ctypes.c_void_p]
 for (M, N, K) in [(512, 4096, 4096), (128, 4096, 4096), (128, 4096, 2048)]:
@@ -22,6 +23,6 @@ for (M, N, K) in [(512, 4096, 4096), (128, 4096, 4096), (128, 4096, 2048)]:
     for t in range(steps):
         ta, tw, tb, tc = host[4 * t], host[4 * t + 1], host[4 * t + 2], host[4 * t + 3]
         nxt = host[4 * (t + 1)] if t + 1 < steps else tc
-        print(f"  step {t:2d}: vmcnt wait {tw - ta:6d}  barrier {tb - tw:6d}  compute {tc - tb:6d} cycles   (to next step {nxt - tc})")
+        if not abl: print(f"  step {t:2d}: vmcnt wait {tw - ta:6d}  barrier {tb - tw:6d}  compute {tc - tb:6d} cycles   (to next step {nxt - tc})")
         tot["wait"] += tw - ta; tot["barrier"] += tb - tw; tot["compute"] += tc - tb; tot["between"] += nxt - tc
-    print("  totals:", tot, "   whole loop:", host[4 * (steps - 1) + 3] - host[0], "cycles")
+    print(f"  abl={abl or 0} totals:", tot, "   whole loop:", host[4 * (steps - 1) + 3] - host[0], "cycles")
