@@ -40,6 +40,12 @@ template <int N, class F> __device__ __forceinline__ void gd_static_for(F &&f) {
     gd_static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F &&>(f));
 }
 
+#ifndef GD_STAMPS
+#define GD_STAMPS 0     // diagnostic builds: 1 the vmcnt wait of barrier 2, 2 barrier 2 itself, 3 the lgkmcnt wait of barrier 1, 4 barrier 1 itself
+#endif
+#if GD_STAMPS
+__device__ unsigned long long g_gd_stamps[16];
+#endif
 constexpr int GD_LDS = 4 * P_IMG;   // A0 A1 B0 B1; the epilogue's store staging (4 x 16.5 KiB) fits inside
 
 // Slot plan of a k-step for a wave tile of 8 (n) x FM (m) fragments of 16 x 16: NS = 16 FM slots, NR = 8 + FM fragment reads
@@ -217,6 +223,10 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, 
     asm volatile("" ::: "memory");
     gd_static_for<Plan::NR>([&](auto n) { read_one(0, std::integral_constant<int, 0>{}, n); });
 
+#if GD_STAMPS
+    uint64_t gd_sum = 0, gd_cnt = 0, gd_t0 = 0;      // diagnostic builds (tools/exp/dense_stamps.hip): cycles of one wait / barrier, summed over the k-steps
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(gd_t0) :: "memory");
+#endif
     // ---- one k-step = Plan::NS fenced slots.  Stage C holds tile j, stage Nn tile j+1 (landing); WO = the wave's slot offset.
     auto kstep = [&](auto cc, auto first, auto wo_, int j, const DmaCtx &dc) {
         constexpr int C = decltype(cc)::value, Nn = C ^ 1, WO = decltype(wo_)::value;
@@ -225,13 +235,29 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, 
         gd_static_for<Plan::NS>([&](auto tt) {
             constexpr int t = decltype(tt)::value, ks = t / (8 * FM), f = (t % (8 * FM)) / FM, g = t % FM;
             if constexpr (t == Plan::B1) {
+#if GD_STAMPS == 3
+                { uint64_t a_, b_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(a_), "=s"(b_) :: "memory"); gd_sum += b_ - a_; gd_cnt++; }
+#else
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+#if GD_STAMPS == 4
+                { uint64_t a_, b_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(a_), "=s"(b_) :: "memory"); gd_sum += b_ - a_; gd_cnt++; }
+#else
                 __builtin_amdgcn_s_barrier();
+#endif
                 asm volatile("" ::: "memory");
             }
             if constexpr (t == Plan::B2) {
+#if GD_STAMPS == 1
+                { uint64_t a_, b_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(%2)\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(a_), "=s"(b_) : "n"(Plan::NP) : "memory"); gd_sum += b_ - a_; gd_cnt++; }
+#else
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Plan::NP) : "memory");
+#endif
+#if GD_STAMPS == 2
+                { uint64_t a_, b_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(a_), "=s"(b_) :: "memory"); gd_sum += b_ - a_; gd_cnt++; }
+#else
                 __builtin_amdgcn_s_barrier();
+#endif
                 asm volatile("" ::: "memory");
             }
             if constexpr (I8) {
@@ -275,6 +301,16 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, 
         else main_loop(std::integral_constant<int, 1>{});
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if GD_STAMPS
+    {
+        uint64_t gd_t1;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(gd_t1) :: "memory");
+        if (blockIdx.x == 17 && (threadIdx.x & 63) == 0) {
+            unsigned long long *o = g_gd_stamps + 4 * (threadIdx.x >> 6);
+            o[0] = gd_sum; o[1] = gd_cnt; o[2] = gd_t1 - gd_t0;
+        }
+    }
+#endif
 
     // ---- epilogue: acc[f][g][r] = out[m0 + 16 FM wm + 16 g + (lane & 15)][n0 + 128 wn + 16 f + 4 (lane >> 4) + r]
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -18,3 +18,6 @@ extern "C" int exp_dense(const void *X, const void *Wd, void *out, int64_t M, in
                        static_cast<const float *>(nullptr), OutlierEpilogue{});
     return (int)hipGetLastError();
 }
+#if GD_STAMPS
+extern "C" int exp_dense_stamps(unsigned long long *host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_gd_stamps), sizeof(unsigned long long) * 16); }
+#endif
