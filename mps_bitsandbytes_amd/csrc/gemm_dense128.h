@@ -18,6 +18,13 @@
 
 namespace mbnb {
 
+#ifndef G128_STAMPS
+#define G128_STAMPS 0     // diagnostic builds: 1 the vmcnt wait of the k-step's barrier, 2 the barrier itself
+#endif
+#if G128_STAMPS
+__device__ unsigned long long g_d128_stamps[16];
+#endif
+
 constexpr int G128_STAGE = 32768;            // A image 16 KiB (128 rows x 128 B) + B image 16 KiB
 constexpr int G128_LDS = 3 * G128_STAGE;     // the epilogue's staging (4 x 64 rows x 136 B) fits inside
 
@@ -134,6 +141,10 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense128(const T *__restrict__ 
     asm volatile("" ::: "memory");
     gd_static_for<16>([&](auto n) { read_frag(0, I0{}, n); });
 
+#if G128_STAMPS
+    uint64_t g_sum = 0, g_cnt = 0, g_t0 = 0;      // diagnostic builds (tools/exp/d128_stamps.hip)
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(g_t0) :: "memory");
+#endif
     // ---- one k-step: tile j in registers (parity P), tile j+1 in stage s1 (landing), tile j+2 requested into stage s2
     auto kstep = [&](auto pp, auto first, auto wo_, int s1, int s2, int j, const DmaCtx &dc) {
         constexpr int P = decltype(pp)::value, WO = decltype(wo_)::value;
@@ -145,9 +156,17 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense128(const T *__restrict__ 
             if constexpr (t == 18) {
                 // tile j+1 (requested one k-step ago) has landed for this wave; behind the barrier for all of them -- and every wave
                 // has finished reading tile j-1's stage... (its reads were issued in k-step j-1 and waited for by its MFMAs)
+#if G128_STAMPS == 1
+                { uint64_t a_, b_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(8)\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(a_), "=s"(b_) :: "memory"); g_sum += b_ - a_; g_cnt++; }
+#else
                 asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#endif
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the reads of tile j (issued a k-step ago) are complete: free by now
+#if G128_STAMPS == 2
+                { uint64_t a_, b_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(a_), "=s"(b_) :: "memory"); g_sum += b_ - a_; g_cnt++; }
+#else
                 __builtin_amdgcn_s_barrier();
+#endif
                 asm volatile("" ::: "memory");
             }
             if constexpr (FIRST && ks == 0) mfma_zero(acc[f][g], wf[P][ks][f], xf[P][ks][g]);
@@ -181,6 +200,16 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense128(const T *__restrict__ 
     if ((wave & 1) == 0) main_loop(I0{});
     else main_loop(I1{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if G128_STAMPS
+    {
+        uint64_t g_t1;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(g_t1) :: "memory");
+        if (blockIdx.x == 17 && (threadIdx.x & 63) == 0) {
+            unsigned long long *o = g_d128_stamps + 4 * (threadIdx.x >> 6);
+            o[0] = g_sum; o[1] = g_cnt; o[2] = g_t1 - g_t0;
+        }
+    }
+#endif
 
     // ---- epilogue: acc[f][g][r] = out[m0 + 64 wm + 16 g + (lane & 15)][n0 + 64 wn + 16 f + 4 (lane >> 4) + r]
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
