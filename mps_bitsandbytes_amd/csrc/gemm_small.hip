@@ -18,27 +18,30 @@ bool gemm_small8_shape(int64_t M, int64_t N, int64_t K) { return small_shape_up_
 // in (activation tile 16 MF rows x 256 k per step against 32 NF bytes of weights per lane), so per step a workgroup costs
 // about  0.4 us + its activation KiB / 55 GB/s  (small_check.py: 64 KiB -> 1.6 us, 32 KiB -> 1.0 us), a slice pays a prologue
 // of ~2.5 us, and every extra slice adds M x N x 4 bytes of partials written and read (6 TB/s).
-struct SmallPlan { int nf; int64_t slices; };
+struct SmallPlan { int nf; int64_t slices; double us; };
+// Round 3 (after the weights streamed in and the pipeline crossed the step boundary; tools/exp/small_stamps.py, small_nf2.py): a step of the 64-row
+// form (NF = 1, 64 MFMAs per wave) takes ~3400 cycles = 1.5-1.6 us whatever the slice length, a step of the 128-row form (NF = 2, 128 MFMAs) ~4760 =
+// 2.1 us with half the CUs busy and ~3.0 us with all of them (512 x 8192 x 4096: 50.8 us) -- 10-30 % less per weight row, because the activation tile (the
+// CU's inflow limit) is taken in once for twice the rows.  The 128-row form
+// halves the workgroups, so it pays where the 64-row form would need a second round (512 x 8192 x 4096: 256 workgroups instead of 512).
 SmallPlan gemm_small_plan(int64_t M, int64_t N, int64_t K, int maxs_mf8 = 16) {
     const int64_t mf = M > 64 ? 8 : 4, mt = (M + 16 * mf - 1) / (16 * mf), steps = K / 256;
-    SmallPlan best{1, 1};
+    SmallPlan best{1, 1, 1e30};
     double best_t = 1e30;
-    for (int nf = 1; nf <= 1; nf++) {   // nf = 2 (128 weight rows per workgroup) measured slower on every shape: small_check.py in round 2 (M <= 256), and
-                                        // again in round 3 above 256 rows (512 x 4096 x 2048: 29.8 us against 19.2; a step of 128 MFMAs per wave takes 3.4 us)
-        const int64_t wgs = ((N + 64 * nf - 1) / (64 * nf)) * mt, maxs = nf == 1 ? (mf == 8 ? maxs_mf8 : 8) : 8;   // 16: k_gemm_small<.., MAXS_ = 16>
-        const double step_us = 0.4 * nf + (double)(mf * 8) / 55.0;     // KiB of activations per step = 16 mf x 512 / 1024 = 8 mf
+    const int nf_max = (M > 256 && maxs_mf8 == 16) ? 2 : 1;      // NF = 2: k_gemm_small<.., 8, 2, 16> (the 4-bit form above 256 rows)
+    for (int nf = 1; nf <= nf_max; nf++) {
+        const int64_t wgs = ((N + 64 * nf - 1) / (64 * nf)) * mt, maxs = mf == 8 ? maxs_mf8 : 8;
+        const double step_us = nf == 2 ? 3.0 : (M > 256 ? 1.6 : 0.4 + (double)(mf * 8) / 55.0);     // the plans up to 256 rows keep their tuned constants
         for (int64_t s = 1; s <= 16 && s <= steps; s++) {
             const int64_t per = (steps + s - 1) / s;
             if (per > maxs) continue;
-            // more than 8 steps per slice = the 16-step instantiation: 2.06 us per step measured (512 x 4096 x 4096 in one round: 35.5 us)
-            const double su = per > 8 ? step_us * 1.32 : step_us;
             // the reduction launch: 3-4 us + the boundary (288 x 4096 x 4096 in two slices: 38.1 us); the plans up to 256 rows were tuned
             // with 2.0 and keep it
             const double split_fixed = M > 256 ? 5.0 : 2.0;
-            const double t = (double)((wgs * s + 255) / 256) * (2.5 + (double)per * su) + (s > 1 ? 8.0 * (double)s * (double)M * (double)N / 6.0e6 + split_fixed : 0.0);
+            const double t = (double)((wgs * s + 255) / 256) * (2.5 + (double)per * step_us) + (s > 1 ? 8.0 * (double)s * (double)M * (double)N / 6.0e6 + split_fixed : 0.0);
             if (t < best_t - 1e-9) {
                 best_t = t;
-                best = SmallPlan{nf, s};
+                best = SmallPlan{nf, s, t};
             }
         }
     }
@@ -53,7 +56,11 @@ bool gemm_small_one_round(int64_t M, int64_t N, int64_t K, int64_t K_weight, int
     if (M <= 256 || !gemm_small_shape(M, N, K, K_weight)) return false;
     const SmallPlan plan = gemm_small_plan(M, N, K);
     const int64_t wgs = ((N + 64 * plan.nf - 1) / (64 * plan.nf)) * ((M + 127) / 128) * plan.slices;
-    return wgs <= 256 && (plan.slices == 1 || ws_bytes >= plan.slices * M * N * 4);
+    if (wgs > 256 || (plan.slices > 1 && ws_bytes < plan.slices * M * N * 4)) return false;
+    // against what the decode-once path would take: the dequantise pass (2.53 bytes per weight at 4.4 TB/s) + its boundary + 128 x 128 tiles
+    const int64_t tiles2 = ((M + 127) / 128) * ((N + 127) / 128);
+    const double dense_us = (double)N * (double)K_weight * 2.53 / 4.4e6 + 3.6 + (double)((tiles2 + 255) / 256) * (double)(K / 64) * (tiles2 <= 128 ? 0.36 : 0.47) + 2.0;
+    return plan.us < dense_us * 1.05;
 }
 int64_t gemm_small8_slices(int64_t M, int64_t N, int64_t K) { return gemm_small_plan(M, N, K, 8).slices; }
 int64_t gemm_small8_workspace_bytes(int64_t M, int64_t N, int64_t K) {
@@ -98,12 +105,14 @@ int launch_gemm_small(const T *x, const uint8_t *packed, const AbsmaxView &am, c
     SmallPlan plan = gemm_small_plan(M, N, K);
     if (plan.slices > 1 && (ws == nullptr || ws_bytes < plan.slices * M * N * 4 || (reinterpret_cast<uintptr_t>(ws) & 15))) {
         if (K / 256 > (M > 64 ? 16 : 8)) return MBNB_NOT_APPLICABLE;
-        plan = SmallPlan{1, 1};
+        plan = SmallPlan{1, 1, 0.0};
     }
 #define MBNB_SMALL(MF, NF) return launch_gemm_small_mf<T, OutT, NESTED, MF, NF>(x, packed, am, bias, out, M, N, K, K_weight, qt, bs_shift, ws, ws_bytes, plan.slices, st)
     if (M <= 64) {
         MBNB_SMALL(4, 1);
     }
+    if (plan.nf == 2)
+        return launch_gemm_small_mf<T, OutT, NESTED, 8, 2, 16>(x, packed, am, bias, out, M, N, K, K_weight, qt, bs_shift, ws, ws_bytes, plan.slices, st);
     if ((K / 256 + plan.slices - 1) / plan.slices > 8)
         return launch_gemm_small_mf<T, OutT, NESTED, 8, 1, 16>(x, packed, am, bias, out, M, N, K, K_weight, qt, bs_shift, ws, ws_bytes, plan.slices, st);
     MBNB_SMALL(8, 1);

@@ -194,7 +194,7 @@ def test_matmul_splitk_path(case, monkeypatch):
     dict(M=64, N=4096, K=4096, dt=torch.bfloat16, bs=128, cs=True, want="mfma_small_splitk"),    # blocksize 128, double-quantised absmax
     dict(M=150, N=520, K=1024, dt=torch.float16, bs=32, qt="fp4", want="mfma_small_splitk"),     # blocksize 32: one block per lane chunk
     dict(M=100, N=512, K=4096, dt=torch.bfloat16, bs=2048, want="mfma_small_splitk"),            # blocksize 2048: a block spans 8 steps
-    dict(M=384, N=11008, K=4096, dt=torch.bfloat16, cd=torch.float32, want="mfma_small_splitk"), # three m-tiles, f32 output
+    dict(M=384, N=11008, K=4096, dt=torch.bfloat16, cd=torch.float32, want="mfma_small"),        # three m-tiles, f32 output (round 3: the 128-row form, one slice)
     dict(M=300, N=8192, K=256, dt=torch.float16, want="mfma_mid"),                               # 4 k-steps, no split (384 tiles), wide layer
     dict(M=65, N=64, K=256, dt=torch.bfloat16, bias=False, want="mfma_mid"),                     # one tile, K too short to split
 ])
@@ -253,7 +253,7 @@ def test_matmul_mfma256_path(case, monkeypatch):
     dict(M=700, N=3800, K=1088, dt=torch.bfloat16, cd=torch.float32),    # split-K with a short last slice, f32 output
     dict(M=640, N=4096, K=4096, dt=torch.bfloat16),                      # 128 x 128 tiles, 160 of them (512 rows and fewer: k_gemm_small, round 3)
     dict(M=257, N=11008, K=512, dt=torch.float16, cs=True),              # 256 x 128 tiles, ragged M (one row in the third tile)
-    dict(M=512, N=2048, K=8192, dt=torch.bfloat16),                      # few tiles, long K: the plan still splits K (round 3)
+    dict(M=640, N=2048, K=8192, dt=torch.bfloat16),                      # few tiles, long K (512 rows and fewer: k_gemm_small, round 3)
 ])
 def test_matmul_decode_once_path(case, monkeypatch):
     """Large M through the Python API: dequantize_4bit into the scratch + k_gemm_dense (gemm_dense.h), any blocksize / code
@@ -1335,7 +1335,9 @@ def test_matmul_decode_beside_equals_the_two_launch_path(M, N, K, dt, qt, dq, wi
                                                            (300, 1000, 3072, torch.bfloat16, "nf4", False, True, "mfma_small_splitk"),
                                                            (512, 2048, 4096, torch.bfloat16, "nf4", True, False, "mfma_small_splitk"),
                                                            (400, 5120, 4096, torch.bfloat16, "nf4", False, False, "dequant+dense"),
-                                                           (512, 4096, 8192, torch.bfloat16, "nf4", False, False, "dequant+dense_splitk")])
+                                                           (512, 4096, 8192, torch.bfloat16, "nf4", False, False, "mfma_small_splitk"),     # 32 steps in two slices of 16
+                                                           (512, 8192, 2048, torch.bfloat16, "nf4", False, True, "mfma_small"),               # the 128-row form: 256 workgroups
+                                                           (512, 11008, 4096, torch.bfloat16, "nf4", True, False, "dequant+dense")])         # two rounds even of the 128-row form
 def test_matmul_257_to_512_rows_stay_fused_where_one_round_serves_them(M, N, K, dt, qt, dq, with_bias, kern):
     """Round 3: 256 < M <= 512 rows go to k_gemm_small (16 steps of weights in registers: K = 4096 in one slice) where its workgroups
     fit the chip in one round -- 512 x 4096^2 35.6 us against 40.6 for dequantise + dense (profiles/r03_small16_ab.txt) -- and to the

@@ -31,7 +31,7 @@ def graph_us(fn, n=20, reps=7):
 for (M, N, K, cs) in [(257, 4096, 4096, False), (288, 4096, 4096, False), (320, 4096, 4096, False), (384, 4096, 4096, False), (448, 4096, 4096, False), (512, 4096, 4096, False),
                       (512, 4096, 4096, True), (512, 4096, 2048, False), (512, 2048, 4096, False), (400, 5120, 4096, False), (512, 11008, 4096, True), (512, 4096, 8192, False),
                       (640, 4096, 4096, False), (512, 2048, 8192, False), (384, 11008, 4096, False), (300, 1000, 3072, False), (512, 1024, 4096, False), (300, 4096, 1024, False),
-                      (512, 8192, 2048, False), (257, 2048, 2048, False)]:
+                      (512, 8192, 2048, False), (257, 2048, 2048, False), (512, 8192, 4096, False), (384, 8192, 4096, False), (300, 6144, 4096, False), (512, 7168, 2048, False), (512, 8192, 8192, False), (400, 5120, 5120, False)]:
     g = torch.Generator(device=dev); g.manual_seed(M + N)
     W = torch.randn(N, K, generator=g, device=dev).to(torch.bfloat16) * (0.05 if cs else 1.0)
     X = torch.randn(M, K, generator=g, device=dev).to(torch.bfloat16)
