@@ -18,6 +18,9 @@
 
 namespace mbnb {
 
+#ifndef G128_ABL
+#define G128_ABL 0       // diagnostic builds: 1 no LDS-DMA pieces in the loop, 2 no fragment reads in the loop (timing only)
+#endif
 #ifndef G128_STAMPS
 #define G128_STAMPS 0     // diagnostic builds: 1 the vmcnt wait of the k-step's barrier, 2 the barrier itself
 #endif
@@ -172,10 +175,10 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense128(const T *__restrict__ 
             if constexpr (FIRST && ks == 0) mfma_zero(acc[f][g], wf[P][ks][f], xf[P][ks][g]);
             else mfma_acc(acc[f][g], wf[P][ks][f], xf[P][ks][g]);
             // pieces of tile j+2: stage s2 held tile j-1, which every wave finished reading before the barrier of k-step j-1
-            if constexpr (t >= WO && t < WO + 16 && ((t - WO) & 1) == 0)
+            if constexpr (!(G128_ABL & 1) && t >= WO && t < WO + 16 && ((t - WO) & 1) == 0)
                 issue_piece(std::integral_constant<int, ((t - WO) >> 1) & 7>{}, s2, kb2, dc);
             // fragments of tile j+1 (16 reads) behind the barrier: slots 18 .. 31 (two in the first two slots)
-            if constexpr (t >= 18) {
+            if constexpr (!(G128_ABL & 2) && t >= 18) {
                 constexpr int n0_ = t == 18 ? 0 : (t == 19 ? 2 : t - 16);
                 read_frag(s1, PN_{}, std::integral_constant<int, n0_ & 15>{});
                 if constexpr (t < 20) read_frag(s1, PN_{}, std::integral_constant<int, (n0_ + 1) & 15>{});

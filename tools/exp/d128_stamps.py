@@ -10,8 +10,8 @@ for (M, N, K) in [(1024, 4096, 4096), (512, 4096, 4096)]:
     g = torch.Generator(device=dev); g.manual_seed(3)
     x = torch.randn(M, K, generator=g, device=dev).to(torch.bfloat16); w = (torch.randn(N, K, generator=g, device=dev) * 0.05).to(torch.bfloat16)
     out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
-    for v, name in ((1, "vmcnt(8) wait"), (2, "barrier")):
-        lib = ctypes.CDLL(os.path.join(here, f"libd128_st{v}.so"))
+    for v, name in ((1, "vmcnt(8) wait"), (2, "barrier"), ("abl1", "no pieces"), ("abl2", "no frag reads"), ("abl3", "neither")):
+        lib = ctypes.CDLL(os.path.join(here, f"libd128_st{v}.so" if isinstance(v, int) else f"libd128_{v}.so"))
         lib.exp_d128.restype = ctypes.c_int; lib.exp_d128.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int64] * 3 + [ctypes.c_void_p]
         lib.exp_d128_stamps.restype = ctypes.c_int; lib.exp_d128_stamps.argtypes = [ctypes.c_void_p]
         for _ in range(20):
