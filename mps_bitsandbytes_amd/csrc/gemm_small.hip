@@ -4,16 +4,16 @@
 
 namespace mbnb {
 
-static bool small_shape_up_to(int64_t M, int64_t N, int64_t K, int64_t K_weight, int64_t max_m) {
-    // from 33 rows (17 for layers of more than 16 Mi weights) the weight-streaming skinny kernel loses: 64 x 4096 x 4096 12.8 us
-    // here, 18.5 there; 32 x 4096 x 4096 11.8 vs 11.7; 32 x 11008 x 4096 21.7 vs 31.0 (tools/exp/small_check.py)
-    return (M > 32 || (M > 16 && N * K > ((int64_t)1 << 24))) && M <= max_m && K % 256 == 0 && K >= 512 && K <= 16 * 2048 && K_weight % 256 == 0 && N >= 64 &&
+static bool small_shape_up_to(int64_t M, int64_t N, int64_t K, int64_t K_weight, int64_t max_m, int64_t min_m) {
+    // from min_m + 1 rows (17 for layers of more than 16 Mi weights) the weight-streaming skinny kernel loses.  4-bit form, round 3 (streamed weights): 32 x 4096 x 4096
+    // 10.9 us here, 11.5 there; 24 rows 10.5 vs 10.4; 17 rows 9.9 vs 9.1; 32 x 11008 x 4096 21.0 vs 31.0 (tools/exp/small_check.py) -> from 29 rows; the W8A16 form keeps 33
+    return (M > min_m || (M > 16 && N * K > ((int64_t)1 << 24))) && M <= max_m && K % 256 == 0 && K >= 512 && K <= 16 * 2048 && K_weight % 256 == 0 && N >= 64 &&
            256 * K * 2 < ((int64_t)1 << 31);
 }
 // 4-bit weights: up to 512 rows (round 3: k_gemm_small<.., MAXS_ = 16> holds 16 steps of weights in registers -- K = 4096 in one slice,
 // 384 < M <= 512 on a 4096-wide layer = 256 workgroups, one round, no partials); the W8A16 form (gemm_small8.h) keeps 384 rows / 8 steps.
-bool gemm_small_shape(int64_t M, int64_t N, int64_t K, int64_t K_weight) { return small_shape_up_to(M, N, K, K_weight, 512); }
-bool gemm_small8_shape(int64_t M, int64_t N, int64_t K) { return small_shape_up_to(M, N, K, K, 384); }
+bool gemm_small_shape(int64_t M, int64_t N, int64_t K, int64_t K_weight) { return small_shape_up_to(M, N, K, K_weight, 512, 28); }
+bool gemm_small8_shape(int64_t M, int64_t N, int64_t K) { return small_shape_up_to(M, N, K, K, 384, 32); }
 // Plan = (NF: n-fragments per wave -> 64 NF weight rows per workgroup; K slices).  The kernel is bound by what a workgroup takes
 // in (activation tile 16 MF rows x 256 k per step against 32 NF bytes of weights per lane), so per step a workgroup costs
 // about  0.4 us + its activation KiB / 55 GB/s  (small_check.py: 64 KiB -> 1.6 us, 32 KiB -> 1.0 us), a slice pays a prologue

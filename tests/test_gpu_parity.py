@@ -153,8 +153,8 @@ def test_matmul_gemv_path(M, dt):
 @pytest.mark.parametrize("case", [
     dict(M=2, N=4096, K=4096, dt=torch.bfloat16), dict(M=7, N=1000, K=384, dt=torch.float16, qt="fp4", cs=True),
     dict(M=16, N=11008, K=4096, dt=torch.bfloat16, cs=True), dict(M=17, N=48, K=128, dt=torch.float16, bs=32),
-    dict(M=32, N=4096, K=1024, dt=torch.float16, cd=torch.float32), dict(M=33, N=512, K=256, dt=torch.bfloat16),
-    dict(M=32, N=4096, K=4096, dt=torch.bfloat16, bs=128),
+    dict(M=28, N=4096, K=1024, dt=torch.float16, cd=torch.float32), dict(M=33, N=512, K=256, dt=torch.bfloat16),
+    dict(M=28, N=4096, K=4096, dt=torch.bfloat16, bs=128), dict(M=32, N=4096, K=384, dt=torch.bfloat16),       # (29 rows and up with K % 256 == 0: k_gemm_small, round 3)
 ])
 def test_matmul_skinny_path(case):
     """k_skinny4: 1, 2 and 4 activation tiles of 16 rows, ragged N, nested absmax, both code tables, 1-2 blocks per wave."""
