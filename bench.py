@@ -755,7 +755,8 @@ def measure(args, wl, ctx):
             del layers
         if not args.no_gemv:
             # batch sizes between the two metric shapes (the reference's native path serves M <= 512): one HIP graph of
-            # 8 calls per M, same weight; which kernel served it is recorded next to the time
+            # 24 calls per M (the graph's own launch, ~10 us per replay, is then < 0.5 us of a call), same weight; which kernel served it is recorded
+            # next to the time
             sweep = []
             for Ms in (2, 16, 64, 128, 256, 512, 1024):
                 xs_ = gen_normal(synthetic, (Ms, K), dt, 5000 + Ms, 1.0, dev)
@@ -765,13 +766,13 @@ def measure(args, wl, ctx):
                 with torch.cuda.stream(side):
                     bnb.matmul_4bit(xs_, packed, state)
                     with torch.cuda.graph(gr, stream=side):
-                        for _ in range(8):
+                        for _ in range(24):
                             bnb.matmul_4bit(xs_, packed, state)
                 torch.cuda.current_stream().wait_stream(side)
                 for _ in range(3):
                     gr.replay()
                 torch.cuda.synchronize()
-                us = event_time_ms(gr.replay, 10) / 8 * 1e3
+                us = event_time_ms(gr.replay, 10) / 24 * 1e3
                 sweep.append({"M": Ms, "us": round(us, 2), "kernel": _native.last_kernel()})
             out["batch_sweep"] = sweep
         if not args.no_empirical:
