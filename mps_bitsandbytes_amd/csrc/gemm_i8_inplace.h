@@ -26,6 +26,10 @@
 
 namespace mbnb {
 
+#ifdef GI8_STAMPS     // diagnostic builds (tools/exp/i8_stamps.hip): cycles of the k-loop of workgroup 17's four waves
+__device__ unsigned long long g_gi8_stamps[8];
+#endif
+
 constexpr int GD_B1 = 36, GD_D0 = 36, GD_B2 = 100, GD_R0 = 100;   // slot plan of k_gemm_dense (GdPlan<8>)
 
 typedef int v2i_t __attribute__((ext_vector_type(2)));
@@ -185,11 +189,22 @@ __global__ __launch_bounds__(256, 1) void k_gemm_i8_inplace(const int8_t *__rest
         }
         if (j < nk) kstep(std::integral_constant<int, 1>{}, std::false_type{}, wo, j, dc);
     };
+#ifdef GI8_STAMPS
+    uint64_t gi_t0;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(gi_t0) :: "memory");
+#endif
     if (wave == 0) main_loop(std::integral_constant<int, 0>{});
     else if (wave == 1) main_loop(std::integral_constant<int, 1>{});
     else if (wave == 2) main_loop(std::integral_constant<int, 2>{});
     else main_loop(std::integral_constant<int, 3>{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef GI8_STAMPS
+    {
+        uint64_t gi_t1;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(gi_t1) :: "memory");
+        if (blockIdx.x == 17 && (threadIdx.x & 63) == 0) g_gi8_stamps[threadIdx.x >> 6] = gi_t1 - gi_t0;
+    }
+#endif
 
     // ---- epilogue: acc[f][g][r] = sum for out[m0 + 128 wm + 16 g + (lane & 15)][n0 + 128 wn + 16 f + 4 (lane >> 4) + r]
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
