@@ -27,7 +27,7 @@
 namespace mbnb {
 
 #ifdef GI8_STAMPS     // diagnostic builds (tools/exp/i8_stamps.hip): cycles of the k-loop of workgroup 17's four waves
-__device__ unsigned long long g_gi8_stamps[8];
+__device__ unsigned long long g_gi8_stamps[8 + 4 * 256];
 #endif
 
 constexpr int GD_B1 = 36, GD_D0 = 36, GD_B2 = 100, GD_R0 = 100;   // slot plan of k_gemm_dense (GdPlan<8>)
@@ -43,6 +43,9 @@ __global__ __launch_bounds__(256, 1) void k_gemm_i8_inplace(const int8_t *__rest
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave >> 1, wm = wave & 1;
+#ifdef GI8_STAMPS
+    if (tid == 0) g_gi8_stamps[8 + 4 * blockIdx.x + 0] = wall_clock64();
+#endif
 
     const int64_t tiles_m = (M + 255) >> 8, tiles_n = (N + 255) >> 8;
     const int64_t nwg = tiles_m * tiles_n;
@@ -192,6 +195,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_i8_inplace(const int8_t *__rest
 #ifdef GI8_STAMPS
     uint64_t gi_t0;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(gi_t0) :: "memory");
+    const unsigned long long gi_r1 = wall_clock64();
 #endif
     if (wave == 0) main_loop(std::integral_constant<int, 0>{});
     else if (wave == 1) main_loop(std::integral_constant<int, 1>{});
@@ -203,6 +207,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_i8_inplace(const int8_t *__rest
         uint64_t gi_t1;
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(gi_t1) :: "memory");
         if (blockIdx.x == 17 && (threadIdx.x & 63) == 0) g_gi8_stamps[threadIdx.x >> 6] = gi_t1 - gi_t0;
+        if (threadIdx.x == 0) { g_gi8_stamps[8 + 4 * blockIdx.x + 1] = gi_r1; g_gi8_stamps[8 + 4 * blockIdx.x + 2] = wall_clock64(); }
     }
 #endif
 
@@ -313,6 +318,10 @@ __global__ __launch_bounds__(256, 1) void k_gemm_i8_inplace(const int8_t *__rest
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         });
     }
+#ifdef GI8_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0) g_gi8_stamps[8 + 4 * blockIdx.x + 3] = wall_clock64();
+#endif
 }
 
 }  // namespace mbnb

@@ -15,4 +15,4 @@ extern "C" int exp_i8(const int8_t *A, const int8_t *B, const float *sA, const f
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), GD_LDS, static_cast<hipStream_t>(stream), A, B, sA, sB, static_cast<bf16_t *>(out), M, N, K);
     return (int)hipGetLastError();
 }
-extern "C" int exp_i8_stamps(unsigned long long *host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_gi8_stamps), sizeof(unsigned long long) * 8); }
+extern "C" int exp_i8_stamps(unsigned long long *host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_gi8_stamps), sizeof(unsigned long long) * (8 + 4 * 256)); }

@@ -19,8 +19,14 @@ e0.record()
 for _ in range(200):
     lib.exp_i8(A.data_ptr(), B.data_ptr(), sA.data_ptr(), sB.data_ptr(), out.data_ptr(), M, N, K, sp)
 e1.record(); e1.synchronize()
-host = (ctypes.c_ulonglong * 8)()
+host = (ctypes.c_ulonglong * (8 + 4 * 256))()
 assert lib.exp_i8_stamps(host) == 0
 us = e0.elapsed_time(e1) / 200 * 1e3
 for wv in range(4):
     print(f"wave {wv}: k-loop {host[wv]} cycles = {host[wv] / 32:.0f} per k-step of 128 MFMAs; kernel {us:.2f} us per call")
+import statistics
+t = [[host[8 + 4 * b + i] for i in range(4)] for b in range(256)]
+t0 = min(r[0] for r in t)
+for name, i in (("start", 0), ("loop begins", 1), ("loop ends", 2), ("end", 3)):
+    v = sorted((r[i] - t0) / 100 for r in t)
+    print(f"{name:12s}: first {v[0]:6.2f}  median {v[128]:6.2f}  last {v[-1]:6.2f} us")
