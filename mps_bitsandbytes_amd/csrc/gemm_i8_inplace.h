@@ -264,12 +264,16 @@ __global__ __launch_bounds__(256, 1) void k_gemm_i8_inplace(const int8_t *__rest
                 for (int e = 0; e < 4; e++) bv_all[f][e] = t[e] / 127.0f;
             }
         }
-        gd_static_for<2>([&](auto hh) {
+        // Round 3: the wave's 128 rows go out in FOUR parts of 32 (two fragments) instead of two of 64 -- the stores of part q are in flight
+        // while part q + 1 is read, converted and scaled (4.5 VALU per output: at two parts the epilogue took 8.8 us where the bf16 GEMM's
+        // takes 6, tools/exp/i8_stamps.py) --, and the two scale products are packed pairs (v_pk_mul_f32: two IEEE products, the same bits).
+        constexpr int NQ = 4, GQ = 8 / NQ;          // parts, fragments of 16 rows per part
+        gd_static_for<NQ>([&](auto hh) {
             constexpr int H = decltype(hh)::value;
-            const int64_t m_base = m0 + wm * 128 + 64 * H;
-            float sa[4];
+            const int64_t m_base = m0 + wm * 128 + 16 * GQ * H;
+            float sa[GQ];
 #pragma unroll
-            for (int g = 0; g < 4; g++) {
+            for (int g = 0; g < GQ; g++) {
                 const int64_t m = m_base + 16 * g + er16;
                 sa[g] = sA[m < M ? m : M - 1] / 127.0f;
             }
@@ -277,21 +281,22 @@ __global__ __launch_bounds__(256, 1) void k_gemm_i8_inplace(const int8_t *__rest
             for (int f = 0; f < 8; f++) {
                 const int nl = 16 * f + 4 * efq;
 #pragma unroll
-                for (int g = 0; g < 4; g++) {
-                    float v[4];
+                for (int g = 0; g < GQ; g++) {
+                    int a[4];
 #pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        int a;
-                        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(a) : "a"(acc[f][4 * H + g][e]));
-                        v[e] = (float)a * sa[g] * bv_all[f][e];
-                    }
-                    *reinterpret_cast<u32x2 *>(wave_lds + (16 * g + er16) * ROWB + nl * 2) = u32x2{pack2<OutT>(v[0], v[1]), pack2<OutT>(v[2], v[3])};
+                    for (int e = 0; e < 4; e++) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(a[e]) : "a"(acc[f][GQ * H + g][e]));
+                    f32x2 v01 = f32x2{(float)a[0], (float)a[1]}, v23 = f32x2{(float)a[2], (float)a[3]};
+                    const f32x2 s2 = f32x2{sa[g], sa[g]};
+                    v01 = v01 * s2 * f32x2{bv_all[f][0], bv_all[f][1]};
+                    v23 = v23 * s2 * f32x2{bv_all[f][2], bv_all[f][3]};
+                    *reinterpret_cast<u32x2 *>(wave_lds + (16 * g + er16) * ROWB + nl * 2) = u32x2{pack2<OutT>(v01[0], v01[1]), pack2<OutT>(v23[0], v23[1])};
                 }
             }
             const int ch = lane_e & 15;
-            u32x4 piece[16];
+            constexpr int NPC = 4 * GQ;            // 16-byte pieces per lane and part: 4 rows per piece index
+            u32x4 piece[NPC];
 #pragma unroll
-            for (int p = 0; p < 16; p++) {
+            for (int p = 0; p < NPC; p++) {
                 const char *srcp = wave_lds + (p * 4 + (lane_e >> 4)) * ROWB + ch * 16;
                 const u32x2 lo = *reinterpret_cast<const u32x2 *>(srcp), hi = *reinterpret_cast<const u32x2 *>(srcp + 8);
                 piece[p] = u32x4{lo[0], lo[1], hi[0], hi[1]};
@@ -300,13 +305,13 @@ __global__ __launch_bounds__(256, 1) void k_gemm_i8_inplace(const int8_t *__rest
             if (n < N) {
                 if (vec_ok && n + 8 <= N) {
 #pragma unroll
-                    for (int p = 0; p < 16; p++) {
+                    for (int p = 0; p < NPC; p++) {
                         const int64_t m = m_base + p * 4 + (lane_e >> 4);
                         if (m < M) __builtin_nontemporal_store(piece[p], reinterpret_cast<u32x4 *>(o16 + m * N + n));
                     }
                 } else {
 #pragma unroll
-                    for (int p = 0; p < 16; p++) {
+                    for (int p = 0; p < NPC; p++) {
                         const int64_t m = m_base + p * 4 + (lane_e >> 4);
                         if (m >= M) continue;
 #pragma unroll
