@@ -242,6 +242,12 @@ constexpr int MBNB_NOT_APPLICABLE = -1000;
 #ifndef GD_M0_GROUP
 #define GD_M0_GROUP 1
 #endif
+// k_gemm_dense's 16-bit epilogue stages the wave's tile through its private LDS in parts of 16 * GD_EPI_GROUPS rows: with one 16-row group
+// per part the first stores leave after 1/8 of the conversions instead of 1/2 (tools/exp/ab_dense_epilogue.py: same bits; 91.9 -> 91.1 us at
+// 4096^3, 29.8 -> 28.6 us at 4000 x 4096 x 1024).  4 (diagnostic builds): two halves of 64 rows.
+#ifndef GD_EPI_GROUPS
+#define GD_EPI_GROUPS 1
+#endif
 void set_error(const char *fmt, ...);
 void set_kernel_name(const char *name);
 int check_launch(const char *what);

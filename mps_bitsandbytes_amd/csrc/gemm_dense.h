@@ -462,13 +462,14 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, 
     // loops (as run-time tests they became four branches per fragment; bias loads in the loops cost a memory latency each)
     auto epilogue16 = [&](auto wo_t, auto wb_t) {
     constexpr bool WO = decltype(wo_t)::value, WB = decltype(wb_t)::value;
-    gd_static_for<FM / 4>([&](auto hh) {
+    constexpr int GP = (FM % GD_EPI_GROUPS == 0) ? GD_EPI_GROUPS : 4;   // 16-row groups per staged part
+    gd_static_for<FM / GP>([&](auto hh) {
         constexpr int H = decltype(hh)::value;
-        const int64_t m_base = m0 + wm * 16 * FM + 64 * H;
-        float sa[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // I8: the four row groups' scales
+        const int64_t m_base = m0 + wm * 16 * FM + 16 * GP * H;
+        float sa[GP] = {};   // I8: the row groups' scales
         if constexpr (I8) {
 #pragma unroll
-            for (int g = 0; g < 4; g++) {
+            for (int g = 0; g < GP; g++) {
                 const int64_t m = m_base + 16 * g + er16;
                 sa[g] = sA[m < M ? m : M - 1] / 127.0f;
             }
@@ -493,12 +494,12 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, 
                 for (int e = 0; e < 4; e++) bv[e] = unpack_lo<T>(bias_all[f][e >> 1] >> (16 * (e & 1)));
             }
 #pragma unroll
-            for (int g = 0; g < 4; g++) {
+            for (int g = 0; g < GP; g++) {
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
                     float sv;
-                    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(sv) : "a"(acc[f][4 * H + g][e]));
+                    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(sv) : "a"(acc[f][GP * H + g][e]));
                     if constexpr (I8) v[e] = (float)__builtin_bit_cast(int, sv) * sa[g] * bv[e];
                     else v[e] = sv + bv[e];
                 }
@@ -516,7 +517,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, 
                         using OFrag = typename Mfma16<OutlT>::frag;
 #pragma unroll
                         for (int c = 0; c < NCH; c++)
-                            o = Mfma16<OutlT>::run(__builtin_bit_cast(OFrag, wfr_all[8 * c + f]), __builtin_bit_cast(OFrag, xfr_all[FM * c + 4 * H + g]), o);
+                            o = Mfma16<OutlT>::run(__builtin_bit_cast(OFrag, wfr_all[8 * c + f]), __builtin_bit_cast(OFrag, xfr_all[FM * c + GP * H + g]), o);
 #pragma unroll
                         for (int e = 0; e < 4; e++) v[e] = rne(rne(v[e]) + rne(o[e]));
                     }
@@ -533,9 +534,9 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, 
             }
         }
         const int ch = lane_e & 15;  // 4 rows x 16 chunks of 16 B per instruction
-        u32x4 piece[16];
+        u32x4 piece[4 * GP];
 #pragma unroll
-        for (int p = 0; p < 16; p++) {
+        for (int p = 0; p < 4 * GP; p++) {
             const char *srcp = wave_lds + (p * 4 + (lane_e >> 4)) * ROWB + ch * 16;
             const u32x2 lo = *reinterpret_cast<const u32x2 *>(srcp), hi = *reinterpret_cast<const u32x2 *>(srcp + 8);
             piece[p] = u32x4{lo[0], lo[1], hi[0], hi[1]};
@@ -544,7 +545,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, 
         if (n < N) {
             if (vec_ok && n + 8 <= N) {
 #pragma unroll
-                for (int p = 0; p < 16; p++) {
+                for (int p = 0; p < 4 * GP; p++) {
                     const int64_t m = m_base + p * 4 + (lane_e >> 4);
                     // non-temporal: the tile's 128 KiB are not read again by this launch, and 256 workgroups store 32 MB at once
                     // (measured 98.5 -> 95.6 us at 4096^3, tools/exp/ab_dense.py variants 1008 / 1040)
@@ -552,7 +553,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, 
                 }
             } else {
 #pragma unroll
-                for (int p = 0; p < 16; p++) {
+                for (int p = 0; p < 4 * GP; p++) {
                     const int64_t m = m_base + p * 4 + (lane_e >> 4);
                     if (m >= M) continue;
 #pragma unroll

@@ -18,6 +18,9 @@
 
 namespace mbnb {
 
+#ifndef G128_EPI_ONE_PART
+#define G128_EPI_ONE_PART 0   // diagnostic builds: 1 = the 16-bit epilogue converts the whole 64-row tile before its first store
+#endif
 #ifndef G128_ABL
 #define G128_ABL 0       // diagnostic builds: 1 no LDS-DMA pieces in the loop, 2 no fragment reads in the loop (timing only)
 #endif
@@ -261,6 +264,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense128(const T *__restrict__ 
             bias_all[f] = u32x2{t[0] | (t[1] << 16), t[2] | (t[3] << 16)};
         }
     }
+#if G128_EPI_ONE_PART
     auto epilogue16 = [&](auto wb_t) {
         constexpr bool WB = decltype(wb_t)::value;
 #pragma unroll
@@ -318,6 +322,63 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense128(const T *__restrict__ 
             }
         }
     };
+#else
+    auto epilogue16 = [&](auto wb_t) {
+        constexpr bool WB = decltype(wb_t)::value;
+        const int ch = lane_e & 7;   // 8 rows x 8 chunks of 16 B per instruction
+        const int64_t n = n_base + ch * 8;
+        // four parts of 16 rows, each through its own rows of the staging: the first stores leave after a quarter of the conversions
+        // (the same split as k_gemm_dense's, common.h GD_EPI_GROUPS)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+#pragma unroll
+            for (int f = 0; f < 4; f++) {
+                const int nl = 16 * f + 4 * efq;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    float sv;
+                    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(sv) : "a"(acc[f][g][e]));
+                    v[e] = sv;
+                    if constexpr (WB) v[e] += unpack_lo<T>(bias_all[f][e >> 1] >> (16 * (e & 1)));
+                }
+                if (!same_out) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] = to_f32(from_f32<T>(v[e]));
+                }
+                u32x2 pk;
+                if (out_dtype == MBNB_F16) pk = u32x2{pack2<f16_t>(v[0], v[1]), pack2<f16_t>(v[2], v[3])};
+                else pk = u32x2{pack2<bf16_t>(v[0], v[1]), pack2<bf16_t>(v[2], v[3])};
+                *reinterpret_cast<u32x2 *>(wave_lds + (16 * g + er16) * ROWB + nl * 2) = pk;
+            }
+            u32x4 piece[2];
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                const char *srcp = wave_lds + (16 * g + p * 8 + (lane_e >> 3)) * ROWB + ch * 16;
+                const u32x2 lo = *reinterpret_cast<const u32x2 *>(srcp), hi = *reinterpret_cast<const u32x2 *>(srcp + 8);
+                piece[p] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+            }
+            if (n < N) {
+                if (vec_ok && n + 8 <= N) {
+#pragma unroll
+                    for (int p = 0; p < 2; p++) {
+                        const int64_t m = m_base + 16 * g + p * 8 + (lane_e >> 3);
+                        if (m < M) __builtin_nontemporal_store(piece[p], reinterpret_cast<u32x4 *>(out + m * N + n));
+                    }
+                } else {
+#pragma unroll
+                    for (int p = 0; p < 2; p++) {
+                        const int64_t m = m_base + 16 * g + p * 8 + (lane_e >> 3);
+                        if (m >= M) continue;
+#pragma unroll
+                        for (int e = 0; e < 8; e++)
+                            if (n + e < N) out[m * N + n + e] = (uint16_t)(piece[p][e >> 1] >> (16 * (e & 1)));
+                    }
+                }
+            }
+        }
+    };
+#endif
     if (bias != nullptr) epilogue16(std::true_type{});
     else epilogue16(std::false_type{});
 }

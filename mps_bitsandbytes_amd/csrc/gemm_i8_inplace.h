@@ -26,6 +26,9 @@
 
 namespace mbnb {
 
+#ifndef GI8_EPI_PARTS
+#define GI8_EPI_PARTS 4   // parts the 16-bit epilogue stores the wave's 128 rows in (4: 32 rows each)
+#endif
 #ifdef GI8_STAMPS     // diagnostic builds (tools/exp/i8_stamps.hip): cycles of the k-loop of workgroup 17's four waves
 __device__ unsigned long long g_gi8_stamps[8 + 4 * 256];
 #endif
@@ -267,7 +270,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_i8_inplace(const int8_t *__rest
         // Round 3: the wave's 128 rows go out in FOUR parts of 32 (two fragments) instead of two of 64 -- the stores of part q are in flight
         // while part q + 1 is read, converted and scaled (4.5 VALU per output: at two parts the epilogue took 8.8 us where the bf16 GEMM's
         // takes 6, tools/exp/i8_stamps.py) --, and the two scale products are packed pairs (v_pk_mul_f32: two IEEE products, the same bits).
-        constexpr int NQ = 4, GQ = 8 / NQ;          // parts, fragments of 16 rows per part
+        constexpr int NQ = GI8_EPI_PARTS, GQ = 8 / NQ;   // parts, fragments of 16 rows per part
         gd_static_for<NQ>([&](auto hh) {
             constexpr int H = decltype(hh)::value;
             const int64_t m_base = m0 + wm * 128 + 16 * GQ * H;
