@@ -35,6 +35,9 @@ template <int N, class F> __device__ __forceinline__ void gs_static_for(F &&f) {
 }
 
 template <int MF> constexpr int gemm_small_lds_bytes() { return 2 * 16 * MF * 512; }
+#ifndef GS_PK_MUL
+#define GS_PK_MUL 0  // 1 (diagnostic builds): one v_pk_mul_f32 per decoded byte instead of two v_mul_f32 -- same bits, SLOWER (27.9 -> 29.0 us at 512 x 4096^2, profiles/r03_small_pk_mul_ab.txt)
+#endif
 #ifndef GS_ABL
 #define GS_ABL 0     // diagnostic builds (tools/exp/small_stamps.hip): 1 no LDS-DMA pieces in the steps, 2 no decode, 4 no fragment reads (timing only)
 #endif
@@ -242,11 +245,19 @@ __global__ __launch_bounds__(256, 1) void k_gemm_small(const T *__restrict__ X, 
             u32x4 o;
 #pragma unroll
             for (int b = 0; b < 4; b++) {
+#if GS_PK_MUL
+                // both products of a byte's pair in one v_pk_mul_f32 (two IEEE products: the same bits)
+                f32x2 pr;
+                const f32x2 sc2 = f32x2{ra[f][j], ra[f][j]};
+                asm("v_pk_mul_f32 %0, %1, %2" : "=v"(pr) : "v"(src[f][b]), "v"(sc2));
+                o[b] = pack2<T>(pr[0], pr[1]);
+#else
                 float p0, p1;
                 const float l0 = src[f][b][0], l1 = src[f][b][1], sc = ra[f][j];
                 asm("v_mul_f32 %0, %1, %2" : "=v"(p0) : "v"(l0), "v"(sc));
                 asm("v_mul_f32 %0, %1, %2" : "=v"(p1) : "v"(l1), "v"(sc));
                 o[b] = pack2<T>(p0, p1);
+#endif
             }
             wf[f] = __builtin_bit_cast(Frag, o);
         });

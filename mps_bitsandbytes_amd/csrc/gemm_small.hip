@@ -18,30 +18,38 @@ bool gemm_small8_shape(int64_t M, int64_t N, int64_t K) { return small_shape_up_
 // in (activation tile 16 MF rows x 256 k per step against 32 NF bytes of weights per lane), so per step a workgroup costs
 // about  0.4 us + its activation KiB / 55 GB/s  (small_check.py: 64 KiB -> 1.6 us, 32 KiB -> 1.0 us), a slice pays a prologue
 // of ~2.5 us, and every extra slice adds M x N x 4 bytes of partials written and read (6 TB/s).
-struct SmallPlan { int nf; int64_t slices; double us; };
+struct SmallPlan { int nf; int64_t slices; double us; int mf; };
 // Round 3 (after the weights streamed in and the pipeline crossed the step boundary; tools/exp/small_stamps.py, small_nf2.py): a step of the 64-row
 // form (NF = 1, 64 MFMAs per wave) takes ~3400 cycles = 1.5-1.6 us whatever the slice length, a step of the 128-row form (NF = 2, 128 MFMAs) ~4760 =
 // 2.1 us with half the CUs busy and ~3.0 us with all of them (512 x 8192 x 4096: 50.8 us) -- 10-30 % less per weight row, because the activation tile (the
 // CU's inflow limit) is taken in once for twice the rows.  The 128-row form
 // halves the workgroups, so it pays where the 64-row form would need a second round (512 x 8192 x 4096: 256 workgroups instead of 512).
 SmallPlan gemm_small_plan(int64_t M, int64_t N, int64_t K, int maxs_mf8 = 16) {
-    const int64_t mf = M > 64 ? 8 : 4, mt = (M + 16 * mf - 1) / (16 * mf), steps = K / 256;
-    SmallPlan best{1, 1, 1e30};
+    const int64_t steps = K / 256;
+    SmallPlan best{1, 1, 1e30, M > 64 ? 8 : 4};
     double best_t = 1e30;
-    const int nf_max = (M > 256 && maxs_mf8 == 16) ? 2 : 1;      // NF = 2: k_gemm_small<.., 8, 2, 16> (the 4-bit form above 256 rows)
-    for (int nf = 1; nf <= nf_max; nf++) {
-        const int64_t wgs = ((N + 64 * nf - 1) / (64 * nf)) * mt, maxs = mf == 8 ? maxs_mf8 : 8;
-        const double step_us = nf == 2 ? 3.0 : (M > 256 ? 1.6 : 0.4 + (double)(mf * 8) / 55.0);     // the plans up to 256 rows keep their tuned constants
-        for (int64_t s = 1; s <= 16 && s <= steps; s++) {
-            const int64_t per = (steps + s - 1) / s;
-            if (per > maxs) continue;
-            // the reduction launch: 3-4 us + the boundary (288 x 4096 x 4096 in two slices: 38.1 us); the plans up to 256 rows were tuned
-            // with 2.0 and keep it
-            const double split_fixed = M > 256 ? 5.0 : 2.0;
-            const double t = (double)((wgs * s + 255) / 256) * (2.5 + (double)per * step_us) + (s > 1 ? 8.0 * (double)s * (double)M * (double)N / 6.0e6 + split_fixed : 0.0);
-            if (t < best_t - 1e-9) {
-                best_t = t;
-                best = SmallPlan{nf, s, t};
+    // Tile heights.  Up to 64 rows: 64 (MF = 4).  Above 256 rows: 128 (MF = 8; NF = 2 there, k_gemm_small<.., 8, 2, 16>).  In between both
+    // are tried (the 4-bit kernel only: maxs_mf8 == 16): 64-row tiles double the workgroups, which often saves the K split and its reduction
+    // launch -- 256 x 4096^2: 256 workgroups x 16 steps in ONE slice 18.0 us against 128 x 2 slices + reduction 22.4
+    // (tools/exp/ab_small_pk.py, ab_small_mf.py).
+    const int mf_lo = M > 64 && (M > 256 || maxs_mf8 != 16) ? 8 : 4, mf_hi = M > 64 ? 8 : 4;
+    for (int mf = mf_lo; mf <= mf_hi; mf += 4) {
+        const int64_t mt = (M + 16 * mf - 1) / (16 * mf);
+        const int nf_max = (M > 256 && maxs_mf8 == 16) ? 2 : 1;
+        for (int nf = 1; nf <= nf_max; nf++) {
+            const int64_t wgs = ((N + 64 * nf - 1) / (64 * nf)) * mt, maxs = mf == 8 ? maxs_mf8 : (M > 64 ? 16 : 8);
+            const double step_us = nf == 2 ? 3.0 : (M > 256 ? 1.6 : 0.4 + (double)(mf * 8) / 55.0);     // the plans up to 256 rows keep their tuned constants
+            for (int64_t s = 1; s <= 16 && s <= steps; s++) {
+                const int64_t per = (steps + s - 1) / s;
+                if (per > maxs) continue;
+                // the reduction launch: 3-4 us + the boundary (288 x 4096 x 4096 in two slices: 38.1 us); the plans up to 256 rows were tuned
+                // with 2.0 and keep it where only one tile height is tried
+                const double split_fixed = M > 256 ? 5.0 : (mf_lo != mf_hi ? 4.5 : 2.0);
+                const double t = (double)((wgs * s + 255) / 256) * (2.5 + (double)per * step_us) + (s > 1 ? 8.0 * (double)s * (double)M * (double)N / 6.0e6 + split_fixed : 0.0);
+                if (t < best_t - 1e-9) {
+                    best_t = t;
+                    best = SmallPlan{nf, s, t, mf};
+                }
             }
         }
     }
@@ -105,12 +113,14 @@ int launch_gemm_small(const T *x, const uint8_t *packed, const AbsmaxView &am, c
     SmallPlan plan = gemm_small_plan(M, N, K);
     if (plan.slices > 1 && (ws == nullptr || ws_bytes < plan.slices * M * N * 4 || (reinterpret_cast<uintptr_t>(ws) & 15))) {
         if (K / 256 > (M > 64 ? 16 : 8)) return MBNB_NOT_APPLICABLE;
-        plan = SmallPlan{1, 1, 0.0};
+        plan = SmallPlan{1, 1, 0.0, M > 64 ? 8 : 4};
     }
 #define MBNB_SMALL(MF, NF) return launch_gemm_small_mf<T, OutT, NESTED, MF, NF>(x, packed, am, bias, out, M, N, K, K_weight, qt, bs_shift, ws, ws_bytes, plan.slices, st)
     if (M <= 64) {
         MBNB_SMALL(4, 1);
     }
+    if (plan.mf == 4)
+        return launch_gemm_small_mf<T, OutT, NESTED, 4, 1, 16>(x, packed, am, bias, out, M, N, K, K_weight, qt, bs_shift, ws, ws_bytes, plan.slices, st);
     if (plan.nf == 2)
         return launch_gemm_small_mf<T, OutT, NESTED, 8, 2, 16>(x, packed, am, bias, out, M, N, K, K_weight, qt, bs_shift, ws, ws_bytes, plan.slices, st);
     if ((K / 256 + plan.slices - 1) / plan.slices > 8)

@@ -163,8 +163,8 @@ def test_matmul_skinny_path(case):
 
 
 @pytest.mark.parametrize("case", [
-    dict(M=256, N=4096, K=4096, dt=torch.bfloat16), dict(M=200, N=1000, K=1024, dt=torch.float16, cs=True, qt="fp4", bs=128),
-    dict(M=640, N=4096, K=2048, dt=torch.bfloat16, cd=torch.float32), dict(M=1024, N=2048, K=4096, dt=torch.float16),
+    dict(M=256, N=4096, K=8192, dt=torch.bfloat16), dict(M=200, N=1000, K=4096, dt=torch.float16, cs=True, qt="fp4", bs=128),   # (round 3: 64-row tiles take
+    dict(M=640, N=4096, K=2048, dt=torch.bfloat16, cd=torch.float32), dict(M=1024, N=2048, K=4096, dt=torch.float16),               # 256 x 4096^2 in ONE slice)
     dict(M=40, N=11008, K=4096, dt=torch.bfloat16, cs=True, bs=32),
 ])
 def test_matmul_splitk_path(case, monkeypatch):
@@ -185,14 +185,17 @@ def test_matmul_splitk_path(case, monkeypatch):
 @pytest.mark.parametrize("case", [
     dict(M=96, N=4096, K=4096, dt=torch.bfloat16, want="mfma_small_splitk"),                     # 64 n-tiles x 4 slices of 4 steps
     dict(M=128, N=4096, K=4096, dt=torch.float16, cs=True, want="mfma_small_splitk"),            # double-quantised absmax
-    dict(M=190, N=1000, K=1024, dt=torch.float16, cs=True, qt="fp4", want="mfma_small_splitk"),  # two m-tiles, ragged M and N, FP4
-    dict(M=133, N=777, K=768, dt=torch.bfloat16, want="mfma_small_splitk"),                      # slices of 2 and 1 steps, odd M and N
-    dict(M=100, N=4096, K=1280, dt=torch.bfloat16, want="mfma_small_splitk"),                    # 5 steps over 3 slices
+    dict(M=190, N=1000, K=2048, dt=torch.float16, cs=True, qt="fp4", want="mfma_small_splitk"),  # three 64-row m-tiles x 4 slices, ragged M and N, FP4
+    dict(M=133, N=777, K=2304, dt=torch.bfloat16, want="mfma_small_splitk"),                     # slices of 2 and 1 steps, odd M and N
+    dict(M=100, N=4096, K=1280, dt=torch.bfloat16, want="mfma_small"),                           # 64-row tiles (round 3), 5 steps in one slice
+    dict(M=190, N=1000, K=1024, dt=torch.float16, cs=True, qt="fp4", want="mfma_small"),         # 64-row tiles, one slice, ragged M and N, FP4
+    dict(M=256, N=4096, K=4096, dt=torch.bfloat16, want="mfma_small"),                           # 256 workgroups x 16 steps, one slice
     dict(M=40, N=11008, K=4096, dt=torch.bfloat16, cs=True, want="mfma_small_splitk"),           # 64-row form (MF = 4), wide layer
     dict(M=64, N=4096, K=4096, dt=torch.bfloat16, want="mfma_small_splitk"),                     # 64-row form, full tile
-    dict(M=256, N=1024, K=2048, dt=torch.float16, bias=False, want="mfma_small_splitk"),         # two full m-tiles, 8-step slices
+    dict(M=256, N=1024, K=2048, dt=torch.float16, bias=False, want="mfma_small"),                # four full 64-row m-tiles, one 8-step slice
+    dict(M=256, N=1024, K=8192, dt=torch.float16, bias=False, want="mfma_small_splitk"),         # two full 128-row m-tiles, 4-step slices
     dict(M=64, N=4096, K=4096, dt=torch.bfloat16, bs=128, cs=True, want="mfma_small_splitk"),    # blocksize 128, double-quantised absmax
-    dict(M=150, N=520, K=1024, dt=torch.float16, bs=32, qt="fp4", want="mfma_small_splitk"),     # blocksize 32: one block per lane chunk
+    dict(M=150, N=520, K=2048, dt=torch.float16, bs=32, qt="fp4", want="mfma_small_splitk"),     # blocksize 32: one block per lane chunk
     dict(M=100, N=512, K=4096, dt=torch.bfloat16, bs=2048, want="mfma_small_splitk"),            # blocksize 2048: a block spans 8 steps
     dict(M=384, N=11008, K=4096, dt=torch.bfloat16, cd=torch.float32, want="mfma_small"),        # three m-tiles, f32 output (round 3: the 128-row form, one slice)
     dict(M=300, N=8192, K=256, dt=torch.float16, want="mfma_mid"),                               # 4 k-steps, no split (384 tiles), wide layer
@@ -398,9 +401,9 @@ def test_matmul_row_independence_and_linearity_full_size():
     Yh = bnb.matmul_4bit(X * 0.5, packed, st)
     big = Y.abs() > 1e-2
     assert torch.equal((Yh * 2)[big], Y[big])
-    # the same rows through the other kernels: GEMV (1 row), skinny MFMA (4, 24 rows), k_gemm_small (150, 240; 500 rows: 16 steps of
-    # weights in registers, one K slice, round 3), decode once on 128 x 128 tiles (700)
-    for rows_n, kern in ((1, "gemv"), (4, "skinny_mfma16"), (24, "skinny_mfma16"), (150, "mfma_small_splitk"), (240, "mfma_small_splitk"), (500, "mfma_small"),
+    # the same rows through the other kernels: GEMV (1 row), skinny MFMA (4, 24 rows), k_gemm_small (96 rows: K split; 150, 240, 500 rows:
+    # 16 steps of weights in registers, one K slice, round 3), decode once on 128 x 128 tiles (700)
+    for rows_n, kern in ((1, "gemv"), (4, "skinny_mfma16"), (24, "skinny_mfma16"), (96, "mfma_small_splitk"), (150, "mfma_small"), (240, "mfma_small"), (500, "mfma_small"),
                          (700, "dequant+dense")):
         yg = bnb.matmul_4bit(X[:rows_n], packed, st)
         assert _native.last_kernel() == kern

@@ -1,0 +1,65 @@
+"""64 < M <= 256: matmul_4bit of two library builds on the same box (argv: label=path ...; default prev = tools/exp/libmbnb_prev.so, new = the
+in-tree library): device time per call from a HIP graph of 20 calls, the kernel that served it, and max |difference| against an f32 matmul of
+the dequantised weight.  Each library runs in its own subprocess (one process loads one libmbnb_hip.so)."""
+import os, sys, statistics, subprocess, json
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+SHAPES = [(65, 4096, 4096), (80, 4096, 4096), (96, 4096, 4096), (128, 4096, 4096), (160, 4096, 4096), (192, 4096, 4096), (224, 4096, 4096), (256, 4096, 4096),
+          (128, 11008, 4096), (256, 11008, 4096), (128, 4096, 11008), (256, 4096, 11008), (256, 4096, 2048), (192, 2048, 4096), (256, 8192, 8192), (100, 5120, 5120),
+          (256, 4096, 1024), (128, 1024, 4096), (64, 4096, 4096), (288, 4096, 4096)]
+
+
+def child(path):
+    sys.path.insert(0, ROOT)
+    import torch
+    from mps_bitsandbytes_amd import _native
+    _native.LIB_PATH = path
+    import mps_bitsandbytes_amd as bnb
+    dev = torch.device("cuda:0")
+
+    def graph_us(fn, n=20, reps=7):
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s):
+                for _ in range(n):
+                    fn()
+            ts = []
+            for _ in range(reps):
+                g.replay()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(s); g.replay(); e1.record(s); e1.synchronize()
+                ts.append(e0.elapsed_time(e1) / n * 1e3)
+        return statistics.median(ts)
+
+    out = {}
+    g = torch.Generator(device=dev); g.manual_seed(11)
+    for (M, N, K) in SHAPES:
+        W = torch.randn(N, K, generator=g, device=dev).to(torch.bfloat16); x = torch.randn(M, K, generator=g, device=dev).to(torch.bfloat16)
+        packed, st = bnb.quantize_nf4(W, blocksize=64)
+        y = bnb.matmul_4bit(x, packed, st)
+        kern = _native.last_kernel() if hasattr(_native, "last_kernel") else "?"
+        ref = x.float() @ bnb.dequantize_nf4(packed, st).float().t()
+        err = float((y.float() - ref).abs().max() / ref.abs().max())
+        out[f"{M}x{N}x{K}"] = (round(graph_us(lambda: bnb.matmul_4bit(x, packed, st)), 2), kern, err)
+    print("RESULT " + json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    if len(sys.argv) == 3 and sys.argv[1] == "--child":
+        child(sys.argv[2]); sys.exit(0)
+    libs = [a.split("=", 1) for a in sys.argv[1:]] or [["prev", os.path.join(ROOT, "tools/exp/libmbnb_prev.so")], ["new", os.path.join(ROOT, "mps_bitsandbytes_amd/libmbnb_hip.so")]]
+    res = {}
+    for label, path in libs:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", path], capture_output=True, text=True, timeout=400)
+        line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
+        if not line:
+            print(label, "FAILED", r.stdout[-2000:], r.stderr[-2000:]); sys.exit(1)
+        res[label] = json.loads(line[0][7:])
+    labels = [l for l, _ in libs]
+    print(f"{'M x N x K':>20s} " + " ".join(f"{l:>10s} us  {'kernel':<20s} {'rel err':>8s}" for l in labels))
+    for (M, N, K) in SHAPES:
+        k = f"{M}x{N}x{K}"
+        print(f"{k:>20s} " + " ".join(f"{res[l][k][0]:10.2f}     {res[l][k][1]:<20s} {res[l][k][2]:8.1e}" for l in labels), flush=True)

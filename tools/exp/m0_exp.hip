@@ -37,3 +37,26 @@ extern "C" int exp_small(const void *X, const uint8_t *packed, const float *absm
                        (int)MBNB_BF16, static_cast<float *>(nullptr), M, N, K, K, K, (int)MBNB_NF4, 6);
     return (int)hipGetLastError();
 }
+
+// exp_small_v: k_gemm_small<bf16, plain, MF, NF, 16> with one K slice (K <= 4096), variant 0..3 = (MF, NF) (8, 1), (4, 1), (2, 1), (8, 2)
+template <int MF, int NF>
+static int small_v(const void *X, const uint8_t *packed, const float *absmax, void *out, int64_t M, int64_t N, int64_t K, void *stream) {
+    auto kern = k_gemm_small<bf16_t, false, MF, NF, 16>;
+    constexpr int lds = gemm_small_lds_bytes<MF>();
+    if (lds_once(reinterpret_cast<const void *>(kern), lds)) return -2;
+    AbsmaxView am{absmax, nullptr, nullptr, 0};
+    const dim3 grid((unsigned)((N + 64 * NF - 1) / (64 * NF)), 1u, (unsigned)((M + 16 * MF - 1) / (16 * MF)));
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, static_cast<hipStream_t>(stream), static_cast<const bf16_t *>(X), packed, am, static_cast<const bf16_t *>(nullptr), out,
+                       (int)MBNB_BF16, static_cast<float *>(nullptr), M, N, K, K, K, (int)MBNB_NF4, 6);
+    return (int)hipGetLastError();
+}
+extern "C" int exp_small_v(const void *X, const uint8_t *packed, const float *absmax, void *out, int64_t M, int64_t N, int64_t K, void *stream, int variant) {
+    if (K > 4096 || K % 256) return -3;
+    switch (variant) {
+        case 0: return small_v<8, 1>(X, packed, absmax, out, M, N, K, stream);
+        case 1: return small_v<4, 1>(X, packed, absmax, out, M, N, K, stream);
+        case 2: return small_v<2, 1>(X, packed, absmax, out, M, N, K, stream);
+        case 3: return small_v<8, 2>(X, packed, absmax, out, M, N, K, stream);
+    }
+    return -4;
+}
