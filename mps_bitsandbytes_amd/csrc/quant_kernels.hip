@@ -985,7 +985,7 @@ int quantize_4bit_dispatch(const void *A, int dtype, int64_t rows, int64_t cols,
 // the pass saved: 1024 x 4096^2 step 44.0 -> 49.8 us, so the stores stay cached).
 template <typename T, int QT, bool NESTED>
 __global__ __launch_bounds__(256) void k_dequantize_4bit_flat(const uint8_t *__restrict__ packed, AbsmaxView am, int64_t ndw, int bs_shift,
-                                                             T *__restrict__ out) {
+                                                             T *__restrict__ out, int write_through) {
     __shared__ float lut[16];
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const bool ok = g < ndw;
@@ -998,20 +998,25 @@ __global__ __launch_bounds__(256) void k_dequantize_4bit_flat(const uint8_t *__r
     u32x4 p;
 #pragma unroll
     for (int j = 0; j < 4; j++) p[j] = pack2<T>(lut[(w >> (8 * j)) & 15] * a, lut[(w >> (8 * j + 4)) & 15] * a);
-    reinterpret_cast<u32x4 *>(out)[g] = p;
+    u32x4 *o = reinterpret_cast<u32x4 *>(out) + g;
+    // write_through (the scratch of a matmul_4bit call with >= 2048 rows): "sc1" stores leave no dirty lines for the end of the launch to
+    // drain before the GEMM's first load -- the step gains 0.5-2.3 us from 2048 rows up (4096^3: 102.8 -> 101.5 us), loses 0.5 us at 1024 rows
+    // where the 128 x 128 tiles re-read the scratch from the writing XCD's L2 (tools/exp/ab_dq4_step.py, profiles/r03_dequant_store_policy_ab.txt)
+    if (write_through) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(o), "v"(p) : "memory");
+    else *o = p;
 }
 
 template <typename T, int QT>
 static int launch_dequantize_4bit(const uint8_t *packed, const AbsmaxView &am, int64_t rows, int64_t cols,
-                                  int64_t cols_padded, int blocksize, void *out, hipStream_t st) {
+                                  int64_t cols_padded, int blocksize, void *out, hipStream_t st, int write_through) {
     if constexpr (sizeof(T) == 2) {
         const int64_t ndw = rows * cols / 8;
         if (cols == cols_padded && cols % 8 == 0 && blocksize >= 8 && cols % blocksize == 0 && aligned16(out) &&
             (reinterpret_cast<uintptr_t>(packed) & 3) == 0 && ndw >= 65536 && (ndw + 255) / 256 <= 0x7FFFFFFF) {
             const dim3 grid((unsigned)((ndw + 255) / 256));
             const int sh = __builtin_ctz((unsigned)blocksize);
-            if (am.i8) hipLaunchKernelGGL((k_dequantize_4bit_flat<T, QT, true>), grid, dim3(256), 0, st, packed, am, ndw, sh, static_cast<T *>(out));
-            else hipLaunchKernelGGL((k_dequantize_4bit_flat<T, QT, false>), grid, dim3(256), 0, st, packed, am, ndw, sh, static_cast<T *>(out));
+            if (am.i8) hipLaunchKernelGGL((k_dequantize_4bit_flat<T, QT, true>), grid, dim3(256), 0, st, packed, am, ndw, sh, static_cast<T *>(out), write_through);
+            else hipLaunchKernelGGL((k_dequantize_4bit_flat<T, QT, false>), grid, dim3(256), 0, st, packed, am, ndw, sh, static_cast<T *>(out), write_through);
             return check_launch("dequantize_4bit");
         }
     }
@@ -1031,10 +1036,10 @@ static int launch_dequantize_4bit(const uint8_t *packed, const AbsmaxView &am, i
 
 int dequantize_4bit_dispatch(const uint8_t *packed, const AbsmaxView &am, int64_t rows, int64_t cols,
                              int64_t cols_padded, int blocksize, int qt, int out_dtype, void *out,
-                             hipStream_t st) {
+                             hipStream_t st, int write_through) {
 #define MBNB_DQ(T)                                                                                              \
-    (qt == MBNB_NF4 ? launch_dequantize_4bit<T, MBNB_NF4>(packed, am, rows, cols, cols_padded, blocksize, out, st) \
-                    : launch_dequantize_4bit<T, MBNB_FP4>(packed, am, rows, cols, cols_padded, blocksize, out, st))
+    (qt == MBNB_NF4 ? launch_dequantize_4bit<T, MBNB_NF4>(packed, am, rows, cols, cols_padded, blocksize, out, st, write_through) \
+                    : launch_dequantize_4bit<T, MBNB_FP4>(packed, am, rows, cols, cols_padded, blocksize, out, st, write_through))
     switch (out_dtype) {
         case MBNB_F16: return MBNB_DQ(f16_t);
         case MBNB_BF16: return MBNB_DQ(bf16_t);

@@ -10,6 +10,9 @@ lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libd
 lib.exp_dq4.restype = ctypes.c_int
 lib.exp_dq4.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_int64] * 2 + [ctypes.c_void_p]
 nlib = _native.lib()
+SHAPES = [(4096, 4096, 4096), (4096, 11008, 4096), (1024, 4096, 4096)]
+if len(sys.argv) > 1 and sys.argv[1] == "--sweep":
+    SHAPES = [(2048, 4096, 4096), (3072, 4096, 4096), (8192, 4096, 4096), (4096, 2048, 2048), (4096, 8192, 4096), (4096, 4096, 11008), (2048, 8192, 8192), (16384, 4096, 4096), (1536, 4096, 4096)]
 sp = torch.cuda.current_stream().cuda_stream
 
 
@@ -22,7 +25,7 @@ def ev(fn, n):
     return e0.elapsed_time(e1) / n * 1e3
 
 
-for (M, N, K) in [(4096, 4096, 4096), (4096, 11008, 4096), (1024, 4096, 4096)]:
+for (M, N, K) in SHAPES:
     g = torch.Generator(device=dev); g.manual_seed(7)
     W = torch.randn(N, K, generator=g, device=dev).to(torch.bfloat16)
     x = torch.randn(M, K, generator=g, device=dev).to(torch.bfloat16)
@@ -37,7 +40,10 @@ for (M, N, K) in [(4096, 4096, 4096), (4096, 11008, 4096), (1024, 4096, 4096)]:
             rc = lib.exp_dq4(v, packed.data_ptr(), st.absmax.data_ptr(), wd.data_ptr(), N, K, sp); assert rc == 0, rc
             rc = nlib.mbnb_gemm_dense(x.data_ptr(), wd.data_ptr(), 1, None, 1, out.data_ptr(), M, N, K, K, ws.data_ptr(), ws.numel(), 0, sp); assert rc == 0, rc
         return f
-    legs = {"library matmul_4bit": lambda: bnb.matmul_4bit(x, packed, st), "flat 1 dword + dense": step(1), "flat 2 dwords nt + dense": step(12), "flat 4 dwords nt + dense": step(14)}
+    only = len(sys.argv) > 1 and sys.argv[1] == "--sweep"
+    legs = {"library matmul_4bit": lambda: bnb.matmul_4bit(x, packed, st), "flat 1 dword + dense": step(1), "flat 2 dwords nt + dense": step(12), "flat 1 dword sc0 sc1 + dense": step(21), "flat 1 dword sc1 + dense": step(22), "flat 1 dword sc0 + dense": step(23)}
+    if only:
+        legs = {k: legs[k] for k in ("library matmul_4bit", "flat 1 dword + dense", "flat 1 dword sc1 + dense")}
     for name, f in legs.items():
         f(); torch.cuda.synchronize()
         if name != "library matmul_4bit":

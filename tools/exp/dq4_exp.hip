@@ -4,7 +4,7 @@
 // contiguous --, all loads of the UN groups issued before the first decode.  NT: nontemporal stores.
 #include "../../mps_bitsandbytes_amd/csrc/common.h"
 using namespace mbnb;
-template <typename T, int QT, bool NESTED, int UN, bool NT>
+template <typename T, int QT, bool NESTED, int UN, int NT>   // NT: 0 plain stores, 1 nontemporal, 2 write-through "sc0 sc1", 3 "sc1", 4 "sc0"
 __global__ __launch_bounds__(256) void k_dq4_flat(const uint8_t *__restrict__ packed, AbsmaxView am, int64_t ndw, int bs_shift, T *__restrict__ out) {
     __shared__ float lut[16];
     const int tid = threadIdx.x;
@@ -31,7 +31,10 @@ __global__ __launch_bounds__(256) void k_dq4_flat(const uint8_t *__restrict__ pa
             p[j] = pack2<T>(v0, v1);
         }
         u32x4 *o = reinterpret_cast<u32x4 *>(out) + g;
-        if constexpr (NT) __builtin_nontemporal_store(p, o);
+        if constexpr (NT == 1) __builtin_nontemporal_store(p, o);
+        else if constexpr (NT == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(o), "v"(p) : "memory");
+        else if constexpr (NT == 3) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(o), "v"(p) : "memory");
+        else if constexpr (NT == 4) asm volatile("global_store_dwordx4 %0, %1, off sc0" ::"v"(o), "v"(p) : "memory");
         else *o = p;
     }
 }
@@ -41,13 +44,16 @@ extern "C" int exp_dq4(int variant, const uint8_t *packed, const float *absmax, 
     const int64_t ndw = rows * cols / 8;
 #define RUN(UN, NT) hipLaunchKernelGGL((k_dq4_flat<bf16_t, MBNB_NF4, false, UN, NT>), dim3((unsigned)((ndw + 256 * UN - 1) / (256 * UN))), dim3(256), 0, st, packed, am, ndw, 6, static_cast<bf16_t *>(out))
     switch (variant) {
-        case 1: RUN(1, false); break;
-        case 2: RUN(2, false); break;
-        case 4: RUN(4, false); break;
-        case 8: RUN(8, false); break;
-        case 14: RUN(4, true); break;
-        case 18: RUN(8, true); break;
-        case 12: RUN(2, true); break;
+        case 1: RUN(1, 0); break;
+        case 21: RUN(1, 2); break;
+        case 22: RUN(1, 3); break;
+        case 23: RUN(1, 4); break;
+        case 2: RUN(2, 0); break;
+        case 4: RUN(4, 0); break;
+        case 8: RUN(8, 0); break;
+        case 14: RUN(4, 1); break;
+        case 18: RUN(8, 1); break;
+        case 12: RUN(2, 1); break;
         default: return -1;
     }
 #undef RUN
