@@ -248,6 +248,29 @@ constexpr int MBNB_NOT_APPLICABLE = -1000;
 #ifndef GD_EPI_GROUPS
 #define GD_EPI_GROUPS 1
 #endif
+// Cache policy of the 16-bit epilogue stores of k_gemm_dense and k_gemm_dense128 (store_out16).  1 (default): write-through "sc1" -- the tile's
+// bytes are not read again by this launch and leave nothing for the end of the launch to drain (tools/exp/ab_dense_store.py: k_gemm_dense alone
+// 93.9 -> 93.8 us, inside the step 104.5 -> 103.8 us at 4096^3, 284.0 -> 283.1 at 11008 x 4096; ab_epilogue_store.py: the 1024-row step on
+// k_gemm_dense128 43.0 -> 42.1 us).  Diagnostic builds: 0 nontemporal (round 2: 98.5 -> 95.6 us against plain stores), 2 "sc1 nt",
+// 3 "sc0 sc1 nt", 4 plain.  k_gemm_i8_inplace keeps nontemporal stores (store_out16_nt; "sc1" there: 53.0 -> 53.6 us), and so do the
+// kernels that are off by default (not measured).
+#ifndef GD_EPI_STORE
+#define GD_EPI_STORE 1
+#endif
+__device__ __forceinline__ void store_out16_nt(u32x4 *dst, u32x4 v) { __builtin_nontemporal_store(v, dst); }
+__device__ __forceinline__ void store_out16(u32x4 *dst, u32x4 v) {
+#if GD_EPI_STORE == 0
+    __builtin_nontemporal_store(v, dst);
+#elif GD_EPI_STORE == 1
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
+#elif GD_EPI_STORE == 2
+    asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(dst), "v"(v) : "memory");
+#elif GD_EPI_STORE == 3
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(dst), "v"(v) : "memory");
+#else
+    *dst = v;
+#endif
+}
 void set_error(const char *fmt, ...);
 void set_kernel_name(const char *name);
 int check_launch(const char *what);

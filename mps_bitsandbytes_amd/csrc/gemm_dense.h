@@ -547,9 +547,9 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, 
 #pragma unroll
                 for (int p = 0; p < 4 * GP; p++) {
                     const int64_t m = m_base + p * 4 + (lane_e >> 4);
-                    // non-temporal: the tile's 128 KiB are not read again by this launch, and 256 workgroups store 32 MB at once
-                    // (measured 98.5 -> 95.6 us at 4096^3, tools/exp/ab_dense.py variants 1008 / 1040)
-                    if (m < M) __builtin_nontemporal_store(piece[p], reinterpret_cast<u32x4 *>(out + m * N + n));
+                    // not read again by this launch, and 256 workgroups store 32 MB at once: write-through (common.h GD_EPI_STORE; round 2's
+                    // nontemporal stores: 98.5 -> 95.6 us at 4096^3 against plain ones, tools/exp/ab_dense.py variants 1008 / 1040)
+                    if (m < M) store_out16(reinterpret_cast<u32x4 *>(out + m * N + n), piece[p]);
                 }
             } else {
 #pragma unroll

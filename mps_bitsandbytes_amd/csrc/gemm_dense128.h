@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense128(const T *__restrict__ 
 #pragma unroll
                 for (int p = 0; p < 8; p++) {
                     const int64_t m = m_base + p * 8 + (lane_e >> 3);
-                    if (m < M) __builtin_nontemporal_store(piece[p], reinterpret_cast<u32x4 *>(out + m * N + n));
+                    if (m < M) store_out16(reinterpret_cast<u32x4 *>(out + m * N + n), piece[p]);
                 }
             } else {
 #pragma unroll
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense128(const T *__restrict__ 
 #pragma unroll
                     for (int p = 0; p < 2; p++) {
                         const int64_t m = m_base + 16 * g + p * 8 + (lane_e >> 3);
-                        if (m < M) __builtin_nontemporal_store(piece[p], reinterpret_cast<u32x4 *>(out + m * N + n));
+                        if (m < M) store_out16(reinterpret_cast<u32x4 *>(out + m * N + n), piece[p]);
                     }
                 } else {
 #pragma unroll

@@ -584,7 +584,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_fused4(const T *__restrict__ X,
 #pragma unroll
                     for (int p = 0; p < 16; p++) {
                         const int64_t m = m_base + p * 4 + (lane_e >> 4);
-                        if (m < M) __builtin_nontemporal_store(piece[p], reinterpret_cast<u32x4 *>(out + m * N + n));
+                        if (m < M) store_out16_nt(reinterpret_cast<u32x4 *>(out + m * N + n), piece[p]);
                     }
                 } else {
 #pragma unroll

@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_i8_inplace(const int8_t *__rest
 #pragma unroll
                     for (int p = 0; p < NPC; p++) {
                         const int64_t m = m_base + p * 4 + (lane_e >> 4);
-                        if (m < M) __builtin_nontemporal_store(piece[p], reinterpret_cast<u32x4 *>(o16 + m * N + n));
+                        if (m < M) store_out16_nt(reinterpret_cast<u32x4 *>(o16 + m * N + n), piece[p]);
                     }
                 } else {
 #pragma unroll
