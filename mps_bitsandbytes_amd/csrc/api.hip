@@ -57,7 +57,7 @@ int check_launch(const char *what) {
 // launchers (quant_kernels.hip, matmul4_kernels.hip, int8_kernels.hip)
 int quantize_4bit_dispatch(const void *, int, int64_t, int64_t, int64_t, int, int, const float *, uint8_t *, float *, hipStream_t);
 int quantize_4bit_dq_dispatch(const void *, int, int64_t, int64_t, int64_t, int, int, uint8_t *, int8_t *, float *, hipStream_t);
-int dequantize_4bit_dispatch(const uint8_t *, const AbsmaxView &, int64_t, int64_t, int64_t, int, int, int, void *, hipStream_t, int write_through = 0);
+int dequantize_4bit_dispatch(const uint8_t *, const AbsmaxView &, int64_t, int64_t, int64_t, int, int, int, void *, hipStream_t, int store_policy = 0);
 int quantize_blockwise_dispatch(const void *, int, int64_t, int, const float *, int8_t *, float *, hipStream_t);
 int dequantize_blockwise_dispatch(const int8_t *, int64_t, const float *, int, int, void *, hipStream_t);
 int dequant_absmax_dispatch(const void *, int, int64_t, int64_t, const float *, int64_t, int, float *, hipStream_t);

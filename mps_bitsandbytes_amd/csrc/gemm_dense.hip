@@ -11,7 +11,7 @@
 
 namespace mbnb {
 
-int dequantize_4bit_dispatch(const uint8_t *, const AbsmaxView &, int64_t, int64_t, int64_t, int, int, int, void *, hipStream_t, int write_through = 0);
+int dequantize_4bit_dispatch(const uint8_t *, const AbsmaxView &, int64_t, int64_t, int64_t, int, int, int, void *, hipStream_t, int store_policy = 0);
 
 // The policy, from tools/exp/sweep_dense.py (profiles/r02_dense_sweep.txt, r02_dense_sweep2.txt, r02_dense_sweep3.txt).  The
 // path is taken from 256 rows and 1.5 M outputs up (gemm_dense_shape; below that the fused split-K kernels win).  A plan = (wave-tile m fragments FM: 8 -> 256 x 256 tiles, 4 -> 256 n x 128 m tiles; K slices s), the
@@ -138,7 +138,7 @@ int matmul_4bit_dense_path(const void *A, int64_t M, int64_t K, const uint8_t *p
     if (plan.slices > 1 && ws_bytes < wd_bytes + plan.slices * M * N * 4) plan.slices = 1;   // a short workspace costs the split, not the path
     const int64_t slices = plan.slices;
     char *wsb = static_cast<char *>(ws);
-    if (int rc = dequantize_4bit_dispatch(packed, am, N, K_weight, K_weight, blocksize, qt, w_dtype, wsb, st, M >= 2048 ? 1 : 0)) return rc;
+    if (int rc = dequantize_4bit_dispatch(packed, am, N, K_weight, K_weight, blocksize, qt, w_dtype, wsb, st, N * K_weight <= (int64_t(1) << 25) ? 2 : (M >= 2048 ? 1 : 0))) return rc;
     float *partial = reinterpret_cast<float *>(wsb + wd_bytes);
     int rc;
     if (w_dtype == MBNB_F16)

@@ -16,7 +16,7 @@
 
 namespace mbnb {
 
-int dequantize_4bit_dispatch(const uint8_t *, const AbsmaxView &, int64_t, int64_t, int64_t, int, int, int, void *, hipStream_t, int write_through = 0);
+int dequantize_4bit_dispatch(const uint8_t *, const AbsmaxView &, int64_t, int64_t, int64_t, int, int, int, void *, hipStream_t, int store_policy = 0);
 
 constexpr int GF_BK = 32;
 constexpr int GF_PITCH = 36;   // floats per LDS row (144 bytes)

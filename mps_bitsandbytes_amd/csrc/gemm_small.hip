@@ -67,7 +67,10 @@ bool gemm_small_one_round(int64_t M, int64_t N, int64_t K, int64_t K_weight, int
     if (wgs > 256 || (plan.slices > 1 && ws_bytes < plan.slices * M * N * 4)) return false;
     // against what the decode-once path would take: the dequantise pass (2.53 bytes per weight at 4.4 TB/s) + its boundary + 128 x 128 tiles
     const int64_t tiles2 = ((M + 127) / 128) * ((N + 127) / 128);
-    const double dense_us = (double)N * (double)K_weight * 2.53 / 4.4e6 + 3.6 + (double)((tiles2 + 255) / 256) * (double)(K / 64) * (tiles2 <= 128 ? 0.36 : 0.47) + 2.0;
+    // (weights of up to 32 Mi elements: the pass runs four dwords per thread with write-through stores, quant_kernels.hip, and the step is
+    // ~3 us shorter: 400 x 5120 x 4096 43.6 -> 39.3 us)
+    const double boundary = N * K_weight <= (int64_t(1) << 25) ? 0.6 : 3.6;
+    const double dense_us = (double)N * (double)K_weight * 2.53 / 4.4e6 + boundary + (double)((tiles2 + 255) / 256) * (double)(K / 64) * (tiles2 <= 128 ? 0.36 : 0.47) + 2.0;
     return plan.us < dense_us * 1.05;
 }
 int64_t gemm_small8_slices(int64_t M, int64_t N, int64_t K) { return gemm_small_plan(M, N, K, 8).slices; }

@@ -983,40 +983,62 @@ int quantize_4bit_dispatch(const void *A, int dtype, int64_t rows, int64_t cols,
 // 8.17 us; inside the M = 1024 / 4096 steps -1.4 / -0.7 us (tools/exp/ab_dq4.py, ab_dq4_step.py, profiles/r03_dequant_flat_ab.txt; the
 // same kernel with NONTEMPORAL stores runs 6.7 us -- the rate of a plain fill -- but the GEMM that reads the scratch next then pays more than
 // the pass saved: 1024 x 4096^2 step 44.0 -> 49.8 us, so the stores stay cached).
-template <typename T, int QT, bool NESTED>
+template <typename T, int QT, bool NESTED, int UN>
 __global__ __launch_bounds__(256) void k_dequantize_4bit_flat(const uint8_t *__restrict__ packed, AbsmaxView am, int64_t ndw, int bs_shift,
                                                              T *__restrict__ out, int write_through) {
     __shared__ float lut[16];
-    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const bool ok = g < ndw;
-    // the packed dword and its absmax are requested before the code table is filled (its barrier sits under the HBM round trip)
-    const uint32_t w = ok ? reinterpret_cast<const uint32_t *>(packed)[g] : 0u;
-    const float a = ok ? load_absmax<NESTED>(am, (g * 8) >> bs_shift) : 0.0f;
+    // thread t handles dwords t + 256 u (u < UN) of the workgroup's contiguous run of 256 UN: every load instruction of a wave reads 256
+    // contiguous bytes, every store instruction writes 1 KiB; the packed dwords and their absmax are requested before the code table is
+    // filled (its barrier sits under the HBM round trip)
+    const int64_t base = (int64_t)blockIdx.x * (256 * UN) + threadIdx.x;
+    uint32_t w[UN];
+    float a[UN];
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+        const int64_t g = base + 256 * u;
+        const bool ok = g < ndw;
+        w[u] = ok ? reinterpret_cast<const uint32_t *>(packed)[g] : 0u;
+        a[u] = ok ? load_absmax<NESTED>(am, (g * 8) >> bs_shift) : 0.0f;
+    }
     fill_code_lut<QT>(lut, threadIdx.x);
     __syncthreads();
-    if (!ok) return;
-    u32x4 p;
 #pragma unroll
-    for (int j = 0; j < 4; j++) p[j] = pack2<T>(lut[(w >> (8 * j)) & 15] * a, lut[(w >> (8 * j + 4)) & 15] * a);
-    u32x4 *o = reinterpret_cast<u32x4 *>(out) + g;
-    // write_through (the scratch of a matmul_4bit call with >= 2048 rows): "sc1" stores leave no dirty lines for the end of the launch to
-    // drain before the GEMM's first load -- the step gains 0.5-2.3 us from 2048 rows up (4096^3: 102.8 -> 101.5 us), loses 0.5 us at 1024 rows
-    // where the 128 x 128 tiles re-read the scratch from the writing XCD's L2 (tools/exp/ab_dq4_step.py, profiles/r03_dequant_store_policy_ab.txt)
-    if (write_through) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(o), "v"(p) : "memory");
-    else *o = p;
+    for (int u = 0; u < UN; u++) {
+        const int64_t g = base + 256 * u;
+        if (g >= ndw) continue;
+        u32x4 p;
+#pragma unroll
+        for (int j = 0; j < 4; j++) p[j] = pack2<T>(lut[(w[u] >> (8 * j)) & 15] * a[u], lut[(w[u] >> (8 * j + 4)) & 15] * a[u]);
+        u32x4 *o = reinterpret_cast<u32x4 *>(out) + g;
+        // write_through (the scratch of a matmul_4bit call): "sc1" stores leave no dirty lines for the end of the launch to drain before the
+        // GEMM's first load (tools/exp/ab_dq4_step.py, profiles/r03_dequant_store_policy_ab.txt)
+        if (write_through) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(o), "v"(p) : "memory");
+        else *o = p;
+    }
 }
 
 template <typename T, int QT>
 static int launch_dequantize_4bit(const uint8_t *packed, const AbsmaxView &am, int64_t rows, int64_t cols,
-                                  int64_t cols_padded, int blocksize, void *out, hipStream_t st, int write_through) {
+                                  int64_t cols_padded, int blocksize, void *out, hipStream_t st, int store_policy) {
     if constexpr (sizeof(T) == 2) {
         const int64_t ndw = rows * cols / 8;
         if (cols == cols_padded && cols % 8 == 0 && blocksize >= 8 && cols % blocksize == 0 && aligned16(out) &&
             (reinterpret_cast<uintptr_t>(packed) & 3) == 0 && ndw >= 65536 && (ndw + 255) / 256 <= 0x7FFFFFFF) {
-            const dim3 grid((unsigned)((ndw + 255) / 256));
             const int sh = __builtin_ctz((unsigned)blocksize);
-            if (am.i8) hipLaunchKernelGGL((k_dequantize_4bit_flat<T, QT, true>), grid, dim3(256), 0, st, packed, am, ndw, sh, static_cast<T *>(out), write_through);
-            else hipLaunchKernelGGL((k_dequantize_4bit_flat<T, QT, false>), grid, dim3(256), 0, st, packed, am, ndw, sh, static_cast<T *>(out), write_through);
+            // store_policy (internal; the public dequantize_4bit passes 0): 0 = one dword per thread, cached stores (the fastest pass on its
+            // own: 8.2 us at 4096^2); 1 = the same with write-through stores; 2 = FOUR dwords per thread + write-through stores -- a quarter
+            // of the workgroups; slower alone, but the GEMM behind it starts earlier: the step gains 1.5-4.4 us on weights of up to 32 Mi
+            // elements (600 x 4096^2 40.4 -> 36.0 us, 1024 rows 42.1 -> 39.7, 2048 rows 66.9 -> 63.2, 4096 rows 103.3 -> 101.5) and loses
+            // ~1 us on larger ones (8192^2, 11008 x 4096 at 1024 rows), which keep policy 0 / 1
+            if (store_policy == 2) {
+                const dim3 grid((unsigned)((ndw + 1023) / 1024));
+                if (am.i8) hipLaunchKernelGGL((k_dequantize_4bit_flat<T, QT, true, 4>), grid, dim3(256), 0, st, packed, am, ndw, sh, static_cast<T *>(out), 1);
+                else hipLaunchKernelGGL((k_dequantize_4bit_flat<T, QT, false, 4>), grid, dim3(256), 0, st, packed, am, ndw, sh, static_cast<T *>(out), 1);
+            } else {
+                const dim3 grid((unsigned)((ndw + 255) / 256));
+                if (am.i8) hipLaunchKernelGGL((k_dequantize_4bit_flat<T, QT, true, 1>), grid, dim3(256), 0, st, packed, am, ndw, sh, static_cast<T *>(out), store_policy);
+                else hipLaunchKernelGGL((k_dequantize_4bit_flat<T, QT, false, 1>), grid, dim3(256), 0, st, packed, am, ndw, sh, static_cast<T *>(out), store_policy);
+            }
             return check_launch("dequantize_4bit");
         }
     }
@@ -1036,10 +1058,10 @@ static int launch_dequantize_4bit(const uint8_t *packed, const AbsmaxView &am, i
 
 int dequantize_4bit_dispatch(const uint8_t *packed, const AbsmaxView &am, int64_t rows, int64_t cols,
                              int64_t cols_padded, int blocksize, int qt, int out_dtype, void *out,
-                             hipStream_t st, int write_through) {
+                             hipStream_t st, int store_policy) {
 #define MBNB_DQ(T)                                                                                              \
-    (qt == MBNB_NF4 ? launch_dequantize_4bit<T, MBNB_NF4>(packed, am, rows, cols, cols_padded, blocksize, out, st, write_through) \
-                    : launch_dequantize_4bit<T, MBNB_FP4>(packed, am, rows, cols, cols_padded, blocksize, out, st, write_through))
+    (qt == MBNB_NF4 ? launch_dequantize_4bit<T, MBNB_NF4>(packed, am, rows, cols, cols_padded, blocksize, out, st, store_policy) \
+                    : launch_dequantize_4bit<T, MBNB_FP4>(packed, am, rows, cols, cols_padded, blocksize, out, st, store_policy))
     switch (out_dtype) {
         case MBNB_F16: return MBNB_DQ(f16_t);
         case MBNB_BF16: return MBNB_DQ(bf16_t);

@@ -12,7 +12,7 @@ lib.exp_dq4.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_int64]
 nlib = _native.lib()
 SHAPES = [(4096, 4096, 4096), (4096, 11008, 4096), (1024, 4096, 4096)]
 if len(sys.argv) > 1 and sys.argv[1] == "--sweep":
-    SHAPES = [(2048, 4096, 4096), (3072, 4096, 4096), (8192, 4096, 4096), (4096, 2048, 2048), (4096, 8192, 4096), (4096, 4096, 11008), (2048, 8192, 8192), (16384, 4096, 4096), (1536, 4096, 4096)]
+    SHAPES = [(2048, 4096, 4096), (8192, 4096, 4096), (4096, 2048, 2048), (4096, 8192, 4096), (4096, 4096, 11008), (2048, 8192, 8192), (1536, 4096, 4096), (600, 4096, 4096), (1024, 11008, 4096), (1024, 2048, 2048), (768, 5120, 5120)]
 sp = torch.cuda.current_stream().cuda_stream
 
 
@@ -41,9 +41,9 @@ for (M, N, K) in SHAPES:
             rc = nlib.mbnb_gemm_dense(x.data_ptr(), wd.data_ptr(), 1, None, 1, out.data_ptr(), M, N, K, K, ws.data_ptr(), ws.numel(), 0, sp); assert rc == 0, rc
         return f
     only = len(sys.argv) > 1 and sys.argv[1] == "--sweep"
-    legs = {"library matmul_4bit": lambda: bnb.matmul_4bit(x, packed, st), "flat 1 dword + dense": step(1), "flat 2 dwords nt + dense": step(12), "flat 1 dword sc0 sc1 + dense": step(21), "flat 1 dword sc1 + dense": step(22), "flat 1 dword sc0 + dense": step(23)}
+    legs = {"library matmul_4bit": lambda: bnb.matmul_4bit(x, packed, st), "flat 1 dword + dense": step(1), "flat 1 dword sc1 + dense": step(22), "flat 4 dwords + dense": step(4), "flat 8 dwords + dense": step(8), "flat 4 dwords sc1 + dense": step(34), "flat 8 dwords sc1 + dense": step(38), "flat 16 dwords sc1 + dense": step(36)}
     if only:
-        legs = {k: legs[k] for k in ("library matmul_4bit", "flat 1 dword + dense", "flat 1 dword sc1 + dense")}
+        legs = {k: legs[k] for k in ("library matmul_4bit", "flat 1 dword + dense", "flat 1 dword sc1 + dense", "flat 4 dwords + dense", "flat 4 dwords sc1 + dense")}
     for name, f in legs.items():
         f(); torch.cuda.synchronize()
         if name != "library matmul_4bit":

@@ -48,6 +48,10 @@ extern "C" int exp_dq4(int variant, const uint8_t *packed, const float *absmax, 
         case 21: RUN(1, 2); break;
         case 22: RUN(1, 3); break;
         case 23: RUN(1, 4); break;
+        case 32: RUN(2, 3); break;
+        case 34: RUN(4, 3); break;
+        case 38: RUN(8, 3); break;
+        case 36: RUN(16, 3); break;
         case 2: RUN(2, 0); break;
         case 4: RUN(4, 0); break;
         case 8: RUN(8, 0); break;
