@@ -41,7 +41,7 @@ for (M, N, K) in SHAPES:
             rc = nlib.mbnb_gemm_dense(x.data_ptr(), wd.data_ptr(), 1, None, 1, out.data_ptr(), M, N, K, K, ws.data_ptr(), ws.numel(), 0, sp); assert rc == 0, rc
         return f
     only = len(sys.argv) > 1 and sys.argv[1] == "--sweep"
-    legs = {"library matmul_4bit": lambda: bnb.matmul_4bit(x, packed, st), "flat 1 dword + dense": step(1), "flat 1 dword sc1 + dense": step(22), "flat 4 dwords + dense": step(4), "flat 8 dwords + dense": step(8), "flat 4 dwords sc1 + dense": step(34), "flat 8 dwords sc1 + dense": step(38), "flat 16 dwords sc1 + dense": step(36)}
+    legs = {"library matmul_4bit": lambda: bnb.matmul_4bit(x, packed, st), "flat 1 dword sc1 + dense": step(22), "flat 4 dwords sc1 + dense": step(34)}
     if only:
         legs = {k: legs[k] for k in ("library matmul_4bit", "flat 1 dword + dense", "flat 1 dword sc1 + dense", "flat 4 dwords + dense", "flat 4 dwords sc1 + dense")}
     for name, f in legs.items():
