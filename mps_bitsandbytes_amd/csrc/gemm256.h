@@ -115,6 +115,18 @@ __device__ __forceinline__ void store4(OutT *o, const float (&v)[4], int64_t n, 
     }
 }
 
+// Split-K partials (f32): write-through stores -- the next launch (the slice reduction) reads them on other XCDs, and nothing is left for the
+// end of the launch to drain: 0.2-1.3 us per call on the split shapes of k_gemm_small (96 x 4096^2 15.5 -> 14.8 us, 256 x 4096 x 11008
+// 45.1 -> 43.8; two library builds on one box, profiles/r03_small_partials_write_through_ab.txt).
+__device__ __forceinline__ void store4_partial(float *o, const float (&v)[4], int64_t n, int64_t N) {
+    if (n + 4 <= N && ((reinterpret_cast<uintptr_t>(o) & 15) == 0)) {
+        const f32x4 pv = f32x4{v[0], v[1], v[2], v[3]};
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(o), "v"(pv) : "memory");
+    } else {
+        store4(o, v, n, N);
+    }
+}
+
 constexpr int G256_A_BYTES = 256 * ROW_BYTES;
 constexpr int G256_STAGE = 2 * G256_A_BYTES;
 constexpr int G256_LDS = 2 * G256_STAGE + 64;

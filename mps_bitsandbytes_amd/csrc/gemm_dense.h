@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, 
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; e++) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v[e]) : "a"(acc[f][g][e]));
-                if (m < M && nn < N) store4(o + m * N + nn, v, nn, N);
+                if (m < M && nn < N) store4_partial(o + m * N + nn, v, nn, N);
                 __builtin_amdgcn_sched_barrier(0);
             }
         return;

@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_small(const T *__restrict__ X, 
             for (int g = 0; g < MF; g++) {
                 const int64_t m = m0 + 16 * g + r16;
                 float v[4] = {acc[f][g][0], acc[f][g][1], acc[f][g][2], acc[f][g][3]};
-                if (m < M && nn < N) store4(o + m * N + nn, v, nn, N);
+                if (m < M && nn < N) store4_partial(o + m * N + nn, v, nn, N);
             }
             continue;
         }

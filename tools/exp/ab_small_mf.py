@@ -5,7 +5,7 @@ import os, sys, statistics, subprocess, json
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 SHAPES = [(65, 4096, 4096), (80, 4096, 4096), (96, 4096, 4096), (128, 4096, 4096), (160, 4096, 4096), (192, 4096, 4096), (224, 4096, 4096), (256, 4096, 4096),
           (128, 11008, 4096), (256, 11008, 4096), (128, 4096, 11008), (256, 4096, 11008), (256, 4096, 2048), (192, 2048, 4096), (256, 8192, 8192), (100, 5120, 5120),
-          (256, 4096, 1024), (128, 1024, 4096), (64, 4096, 4096), (288, 4096, 4096)]
+          (256, 4096, 1024), (128, 1024, 4096), (64, 4096, 4096), (288, 4096, 4096), (640, 4096, 2048), (1024, 2048, 4096), (320, 8192, 8192)]
 
 
 def child(path):
@@ -44,6 +44,14 @@ def child(path):
         ref = x.float() @ bnb.dequantize_nf4(packed, st).float().t()
         err = float((y.float() - ref).abs().max() / ref.abs().max())
         out[f"{M}x{N}x{K}"] = (round(graph_us(lambda: bnb.matmul_4bit(x, packed, st)), 2), kern, err)
+    for M in (64, 128, 256):
+        Wf = torch.randn(4096, 4096, generator=g, device=dev).to(torch.bfloat16); x = torch.randn(M, 4096, generator=g, device=dev).to(torch.bfloat16)
+        q, sc = bnb.quantize_rowwise(Wf)
+        y = bnb.linear_int8(x, q, sc)
+        kern = _native.last_kernel()
+        ref = x.float() @ bnb.dequantize_rowwise(q, sc).float().t()
+        err = float((y.float() - ref).abs().max() / ref.abs().max())
+        out[f"w8a16 {M}x4096x4096"] = (round(graph_us(lambda: bnb.linear_int8(x, q, sc)), 2), kern, err)
     print("RESULT " + json.dumps(out), flush=True)
 
 
@@ -60,6 +68,6 @@ if __name__ == "__main__":
         res[label] = json.loads(line[0][7:])
     labels = [l for l, _ in libs]
     print(f"{'M x N x K':>20s} " + " ".join(f"{l:>10s} us  {'kernel':<20s} {'rel err':>8s}" for l in labels))
-    for (M, N, K) in SHAPES:
-        k = f"{M}x{N}x{K}"
+    keys = [f"{M}x{N}x{K}" for (M, N, K) in SHAPES] + [f"w8a16 {M}x4096x4096" for M in (64, 128, 256)]
+    for k in keys:
         print(f"{k:>20s} " + " ".join(f"{res[l][k][0]:10.2f}     {res[l][k][1]:<20s} {res[l][k][2]:8.1e}" for l in labels), flush=True)
