@@ -41,7 +41,7 @@ for (M, N, K) in SHAPES:
             rc = nlib.mbnb_gemm_dense(x.data_ptr(), wd.data_ptr(), 1, None, 1, out.data_ptr(), M, N, K, K, ws.data_ptr(), ws.numel(), 0, sp); assert rc == 0, rc
         return f
     only = len(sys.argv) > 1 and sys.argv[1] == "--sweep"
-    legs = {"library matmul_4bit": lambda: bnb.matmul_4bit(x, packed, st), "flat 1 dword sc1 + dense": step(22), "flat 4 dwords sc1 + dense": step(34)}
+    legs = {"library matmul_4bit": lambda: bnb.matmul_4bit(x, packed, st), "flat 1 dword sc1 + dense": step(22), "flat 4 dwords sc1 + dense": step(34), "flat 3 dwords sc1 + dense": step(33), "flat 5 dwords sc1 + dense": step(35), "xcd-contiguous 4 dwords sc1": step(54), "xcd-contiguous 1 dword sc1": step(51)}
     if only:
         legs = {k: legs[k] for k in ("library matmul_4bit", "flat 1 dword + dense", "flat 1 dword sc1 + dense", "flat 4 dwords + dense", "flat 4 dwords sc1 + dense")}
     for name, f in legs.items():

@@ -4,11 +4,13 @@
 // contiguous --, all loads of the UN groups issued before the first decode.  NT: nontemporal stores.
 #include "../../mps_bitsandbytes_amd/csrc/common.h"
 using namespace mbnb;
-template <typename T, int QT, bool NESTED, int UN, int NT>   // NT: 0 plain stores, 1 nontemporal, 2 write-through "sc0 sc1", 3 "sc1", 4 "sc0"
+template <typename T, int QT, bool NESTED, int UN, int NT, bool XMAP = false>   // XMAP: workgroups of one XCD (blockIdx % 8) take a contiguous eighth; NT: 0 plain stores, 1 nontemporal, 2 write-through "sc0 sc1", 3 "sc1", 4 "sc0"
 __global__ __launch_bounds__(256) void k_dq4_flat(const uint8_t *__restrict__ packed, AbsmaxView am, int64_t ndw, int bs_shift, T *__restrict__ out) {
     __shared__ float lut[16];
     const int tid = threadIdx.x;
-    const int64_t base = (int64_t)blockIdx.x * (256 * UN) + tid;
+    const int64_t per = (gridDim.x + 7) / 8;
+    const int64_t bid = XMAP ? (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3) : (int64_t)blockIdx.x;
+    const int64_t base = bid * (256 * UN) + tid;
     uint32_t w[UN];
     float a[UN];
 #pragma unroll
@@ -48,6 +50,10 @@ extern "C" int exp_dq4(int variant, const uint8_t *packed, const float *absmax, 
         case 21: RUN(1, 2); break;
         case 22: RUN(1, 3); break;
         case 23: RUN(1, 4); break;
+        case 54: hipLaunchKernelGGL((k_dq4_flat<bf16_t, MBNB_NF4, false, 4, 3, true>), dim3((unsigned)(((ndw + 1023) / 1024 + 7) / 8 * 8)), dim3(256), 0, st, packed, am, ndw, 6, static_cast<bf16_t *>(out)); break;
+        case 51: hipLaunchKernelGGL((k_dq4_flat<bf16_t, MBNB_NF4, false, 1, 3, true>), dim3((unsigned)(((ndw + 255) / 256 + 7) / 8 * 8)), dim3(256), 0, st, packed, am, ndw, 6, static_cast<bf16_t *>(out)); break;
+        case 33: RUN(3, 3); break;
+        case 35: RUN(5, 3); break;
         case 32: RUN(2, 3); break;
         case 34: RUN(4, 3); break;
         case 38: RUN(8, 3); break;
