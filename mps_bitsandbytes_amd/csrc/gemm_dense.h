@@ -40,6 +40,9 @@ template <int N, class F> __device__ __forceinline__ void gd_static_for(F &&f) {
     gd_static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F &&>(f));
 }
 
+#ifndef GD_ABL
+#define GD_ABL 0        // diagnostic builds (timing only): 1 no LDS-DMA pieces in the k-loop, 2 no fragment reads in the k-loop, 4 no barriers in the k-loop
+#endif
 #ifndef GD_STAMPS
 #define GD_STAMPS 0     // diagnostic builds: 1 the vmcnt wait of barrier 2, 2 barrier 2 itself, 3 the lgkmcnt wait of barrier 1, 4 barrier 1 itself
 #endif
@@ -243,7 +246,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, 
 #if GD_STAMPS == 4
                 { uint64_t a_, b_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(a_), "=s"(b_) :: "memory"); gd_sum += b_ - a_; gd_cnt++; }
 #else
-                __builtin_amdgcn_s_barrier();
+                if constexpr (!(GD_ABL & 4)) __builtin_amdgcn_s_barrier();
 #endif
                 asm volatile("" ::: "memory");
             }
@@ -256,7 +259,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, 
 #if GD_STAMPS == 2
                 { uint64_t a_, b_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(a_), "=s"(b_) :: "memory"); gd_sum += b_ - a_; gd_cnt++; }
 #else
-                __builtin_amdgcn_s_barrier();
+                if constexpr (!(GD_ABL & 4)) __builtin_amdgcn_s_barrier();
 #endif
                 asm volatile("" ::: "memory");
             }
@@ -272,11 +275,11 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, 
             } else {
                 acc[f][g] = Mfma16<T>::run(wf[ks][f], xf[ks][g], acc[f][g]);
             }
-            if constexpr ((t % Plan::RS1) == 0 && t / Plan::RS1 < Plan::NR)
+            if constexpr (!(GD_ABL & 2) && (t % Plan::RS1) == 0 && t / Plan::RS1 < Plan::NR)
                 read_one(C, std::integral_constant<int, 1>{}, std::integral_constant<int, (t / Plan::RS1) % Plan::NR>{});
-            if constexpr (t >= Plan::R0 && t < Plan::R0 + Plan::NR)
+            if constexpr (!(GD_ABL & 2) && t >= Plan::R0 && t < Plan::R0 + Plan::NR)
                 read_one(Nn, std::integral_constant<int, 0>{}, std::integral_constant<int, (t - Plan::R0) % Plan::NR>{});
-            if constexpr (t >= Plan::D0 && t < Plan::D0 + Plan::NP * Plan::DS && ((t - Plan::D0) % Plan::DS) == WO)
+            if constexpr (!(GD_ABL & 1) && t >= Plan::D0 && t < Plan::D0 + Plan::NP * Plan::DS && ((t - Plan::D0) % Plan::DS) == WO)
                 issue_piece(std::integral_constant<int, ((t - Plan::D0) / Plan::DS) % Plan::NP>{}, C, kb2, dc);
             __builtin_amdgcn_sched_barrier(0);
         });
