@@ -668,6 +668,9 @@ def measure(args, wl, ctx):
                 "traffic": traffic.get("k_gemm_dense_bytes_per_launch") if wl == "nf4_m4096" else traffic.get("nf4dq_ffn_gemm_dense_bytes_per_launch"),
                 "note": "k_gemm_dense ALONE on the already dequantised weight (HIP events around K launches / K): NOT the operation the metric names"}
             out["roofline"]["dequantize_us"] = round(deq_us, 2)
+            out["roofline"]["dequantize_us_note"] = ("the public dequantize_4bit launch ALONE (eager call: includes its host side); inside the step the pass stores write-through "
+                                                     "(four dwords per thread on weights of up to 32 Mi elements), see step_minus_dense_us")
+            out["roofline"]["step_minus_dense_us"] = round(out["roofline"]["kernel_us"] - dense_us, 2)
             del Wd, Yd
         if wl == "int8_4096":
             out["roofline"]["launches"] = (["k_gemm_i8_inplace (four waves, B [K, N] read in place: no transpose pass, no workspace)"] if kernel_name == "i8_inplace4"
