@@ -257,6 +257,8 @@ constexpr int MBNB_NOT_APPLICABLE = -1000;
 #ifndef GD_EPI_STORE
 #define GD_EPI_STORE 1
 #endif
+// One aligned 16-byte f32 store, write-through ("sc1"): split-K partials, read next by the reduction launch on other XCDs.
+__device__ __forceinline__ void store_f32x4_wt(float *dst, f32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory"); }
 __device__ __forceinline__ void store_out16_nt(u32x4 *dst, u32x4 v) { __builtin_nontemporal_store(v, dst); }
 __device__ __forceinline__ void store_out16(u32x4 *dst, u32x4 v) {
 #if GD_EPI_STORE == 0

@@ -120,8 +120,7 @@ __device__ __forceinline__ void store4(OutT *o, const float (&v)[4], int64_t n, 
 // 45.1 -> 43.8; two library builds on one box, profiles/r03_small_partials_write_through_ab.txt).
 __device__ __forceinline__ void store4_partial(float *o, const float (&v)[4], int64_t n, int64_t N) {
     if (n + 4 <= N && ((reinterpret_cast<uintptr_t>(o) & 15) == 0)) {
-        const f32x4 pv = f32x4{v[0], v[1], v[2], v[3]};
-        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(o), "v"(pv) : "memory");
+        store_f32x4_wt(o, f32x4{v[0], v[1], v[2], v[3]});
     } else {
         store4(o, v, n, N);
     }

@@ -289,7 +289,7 @@ __global__ __launch_bounds__(512, 4) void k_gemm_mid(const T *__restrict__ X, ty
             const int64_t m = m0 + ml;
             if (m >= M || n >= N) continue;
             const f32x4 v = *reinterpret_cast<const f32x4 *>(smem + ml * PITCH + ch * 16);
-            if (vec_ok && n + 4 <= N) *reinterpret_cast<f32x4 *>(pout + m * N + n) = v;
+            if (vec_ok && n + 4 <= N) store_f32x4_wt(pout + m * N + n, v);   // write-through: gemm256.h store4_partial
             else
                 for (int e = 0; e < 4; e++)
                     if (n + e < N) pout[m * N + n + e] = v[e];

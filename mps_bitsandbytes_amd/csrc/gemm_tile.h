@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_decode(const T *__restrict__ X,
                 if (partial) {
                     // accumulator order: [slice][tile][wave][i*TM+j][g][lane][4] -- a wave's store is 1 KiB contiguous
                     float *pp = partial + (((((int64_t)blockIdx.y * nwg + bid) * 4 + wave) * (TN * TM) + (i * TM + j)) * 4 + g) * 256 + lane * 4;
-                    *reinterpret_cast<f32x4 *>(pp) = f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                    store_f32x4_wt(pp, f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]});   // write-through: gemm256.h store4_partial
                     continue;
                 }
                 float v[4];
