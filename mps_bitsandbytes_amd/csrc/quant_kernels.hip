@@ -711,8 +711,9 @@ __global__ __launch_bounds__(256) void k_dequantize_rows16(const uint8_t *__rest
     float v[16];
 #pragma unroll
     for (int e = 0; e < 16; e++) {
-        const uint32_t b = (w[e >> 2] >> (8 * (e & 3))) & 0xFFu;
-        v[e] = FP8 ? fp8_e4m3_to_float((uint8_t)b) * s : (float)(int)(int8_t)b * s;
+        // FP8: v_cvt_f32_fp8 with its byte select (common.h w8_decode_sel: the same function as fp8_e4m3_to_float on all 256 bytes; the pass is
+        // HBM-bound either way -- tools/exp/ab_w8_sweep.py: no difference inside the LinearFP8 step)
+        v[e] = (FP8 ? w8_decode_sel<W8_FP8>(w[e >> 2], e & 3) : w8_decode_sel<W8_INT8>(w[e >> 2], e & 3)) * s;
     }
     if constexpr (sizeof(T) == 2) {
         u32x4 o0, o1;
