@@ -62,12 +62,12 @@ int quantize_blockwise_dispatch(const void *, int, int64_t, int, const float *, 
 int dequantize_blockwise_dispatch(const int8_t *, int64_t, const float *, int, int, void *, hipStream_t);
 int dequant_absmax_dispatch(const void *, int, int64_t, int64_t, const float *, int64_t, int, float *, hipStream_t);
 int quantize_rowwise_dispatch(const void *, int, int64_t, int64_t, int8_t *, float *, hipStream_t);
-int dequantize_rowwise_dispatch(const int8_t *, const float *, int64_t, int64_t, int, void *, hipStream_t);
+int dequantize_rowwise_dispatch(const int8_t *, const float *, int64_t, int64_t, int, void *, hipStream_t, int store_policy = 0);
 int double_quant_dispatch(const void *, int, int64_t, int64_t, int8_t *, int8_t *, float *, float *, int, int, hipStream_t);
 int matmul_4bit_dispatch(const void *, int64_t, int64_t, const uint8_t *, const AbsmaxView &, int64_t, int64_t, int, int, int, const void *, int, void *, void *, int64_t, int,
                          hipStream_t);
 int quantize_fp8_dispatch(const void *, int, int64_t, int64_t, uint8_t *, float *, hipStream_t);
-int dequantize_fp8_dispatch(const uint8_t *, const float *, int64_t, int64_t, int, void *, hipStream_t);
+int dequantize_fp8_dispatch(const uint8_t *, const float *, int64_t, int64_t, int, void *, hipStream_t, int store_policy = 0);
 int linear_fp8_dispatch(const void *, int, int64_t, int64_t, const uint8_t *, const float *, int64_t, const void *, void *, void *, int64_t, bool, hipStream_t);
 int64_t matmul4_splitk_slices(int64_t, int64_t, int64_t);
 int64_t gemm_mid_workspace_bytes(int64_t, int64_t, int64_t);

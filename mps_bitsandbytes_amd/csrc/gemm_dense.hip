@@ -151,8 +151,8 @@ int matmul_4bit_dense_path(const void *A, int64_t M, int64_t K, const uint8_t *p
     return rc;
 }
 
-int dequantize_rowwise_dispatch(const int8_t *, const float *, int64_t, int64_t, int, void *, hipStream_t);
-int dequantize_fp8_dispatch(const uint8_t *, const float *, int64_t, int64_t, int, void *, hipStream_t);
+int dequantize_rowwise_dispatch(const int8_t *, const float *, int64_t, int64_t, int, void *, hipStream_t, int store_policy = 0);
+int dequantize_fp8_dispatch(const uint8_t *, const float *, int64_t, int64_t, int, void *, hipStream_t, int store_policy = 0);
 
 // Linear8bit.forward / LinearFP8.forward at large M (nn/linear8bit.py:70-102, functional.py:796-807): the reference's own two
 // steps -- dequantize_rowwise / dequantize_fp8_e4m3 into the compute dtype, then F.linear -- on the workspace.  Same policy
@@ -168,8 +168,11 @@ int linear8_dense_path(const void *X, int dtype, int64_t M, int64_t K, const voi
     if (plan.slices > 1 && ws_bytes < wd_bytes + plan.slices * M * N * 4) plan.slices = 1;
     const int64_t slices = plan.slices;
     char *wsb = static_cast<char *>(ws);
-    const int rcq = fp8 ? dequantize_fp8_dispatch(static_cast<const uint8_t *>(W), scales, N, K, dtype, wsb, st)
-                        : dequantize_rowwise_dispatch(static_cast<const int8_t *>(W), scales, N, K, dtype, wsb, st);
+    // the pass's in-step form, as for the 4-bit weights (matmul_4bit_dense_path): four rows per thread + write-through stores on weights of up to
+    // 32 Mi elements, write-through alone from 2048 rows up
+    const int policy = N * K <= (int64_t(1) << 25) ? 2 : (M >= 2048 ? 1 : 0);
+    const int rcq = fp8 ? dequantize_fp8_dispatch(static_cast<const uint8_t *>(W), scales, N, K, dtype, wsb, st, policy)
+                        : dequantize_rowwise_dispatch(static_cast<const int8_t *>(W), scales, N, K, dtype, wsb, st, policy);
     if (rcq) return rcq;
     float *partial = reinterpret_cast<float *>(wsb + wd_bytes);
     int rc;

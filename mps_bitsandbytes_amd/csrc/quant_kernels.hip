@@ -984,6 +984,58 @@ int quantize_4bit_dispatch(const void *A, int dtype, int64_t rows, int64_t cols,
 // 8.17 us; inside the M = 1024 / 4096 steps -1.4 / -0.7 us (tools/exp/ab_dq4.py, ab_dq4_step.py, profiles/r03_dequant_flat_ab.txt; the
 // same kernel with NONTEMPORAL stores runs 6.7 us -- the rate of a plain fill -- but the GEMM that reads the scratch next then pays more than
 // the pass saved: 1024 x 4096^2 step 44.0 -> 49.8 us, so the stores stay cached).
+// The W8A16 / FP8 scratch of the decode-once path (linear8_dense_path), shaped like k_dequantize_4bit_flat's in-step form: a thread takes 8 values
+// of UN consecutive rows (one 8-byte load and ONE 16-byte store each: a wave's store instruction writes 1 KiB contiguous), write-through stores.
+// The same per-element arithmetic as k_dequantize_rows16 (bit-identical).  cols % 8 == 0, q 8-byte and out 16-byte aligned, 16-bit T.
+template <typename T, bool FP8, int UN>
+__global__ __launch_bounds__(256) void k_dequantize_rows8_wt(const uint8_t *__restrict__ q, const float *__restrict__ scales, int64_t rows, int64_t cols,
+                                                            T *__restrict__ out) {
+    const int64_t c0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (c0 >= cols) return;
+    u32x2 w[UN];
+    float s[UN];
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+        const int64_t r = (int64_t)blockIdx.y * UN + u;
+        const bool ok = r < rows;
+        w[u] = ok ? *reinterpret_cast<const u32x2 *>(q + r * cols + c0) : u32x2{0u, 0u};
+        const float sc = ok ? scales[r] : 0.0f;
+        s[u] = FP8 ? sc : sc / 127.0f;  // functional.py:635
+    }
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+        const int64_t r = (int64_t)blockIdx.y * UN + u;
+        if (r >= rows) continue;
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const float v0 = (FP8 ? w8_decode_sel<W8_FP8>(w[u][e >> 1], (2 * e) & 3) : w8_decode_sel<W8_INT8>(w[u][e >> 1], (2 * e) & 3)) * s[u];
+            const float v1 = (FP8 ? w8_decode_sel<W8_FP8>(w[u][e >> 1], (2 * e + 1) & 3) : w8_decode_sel<W8_INT8>(w[u][e >> 1], (2 * e + 1) & 3)) * s[u];
+            o[e] = pack2<T>(v0, v1);
+        }
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(out + r * cols + c0), "v"(o) : "memory");
+    }
+}
+template <bool FP8>
+static bool launch_rows8_wt(const uint8_t *q, const float *scales, int64_t rows, int64_t cols, int out_dtype, void *out, hipStream_t st, int policy) {
+    if (policy == 0 || (out_dtype != MBNB_F16 && out_dtype != MBNB_BF16) || cols % 8 != 0 || rows <= 0 || rows >= 65536 * 4 ||
+        ((reinterpret_cast<uintptr_t>(q) & 7) | (reinterpret_cast<uintptr_t>(out) & 15)) != 0)
+        return false;
+    const unsigned gx = (unsigned)((cols / 8 + 255) / 256);
+    if (policy == 2) {
+        const dim3 grid(gx, (unsigned)((rows + 3) / 4));
+        if (grid.y > 65535u) return false;
+        if (out_dtype == MBNB_F16) hipLaunchKernelGGL((k_dequantize_rows8_wt<f16_t, FP8, 4>), grid, dim3(256), 0, st, q, scales, rows, cols, static_cast<f16_t *>(out));
+        else hipLaunchKernelGGL((k_dequantize_rows8_wt<bf16_t, FP8, 4>), grid, dim3(256), 0, st, q, scales, rows, cols, static_cast<bf16_t *>(out));
+    } else {
+        const dim3 grid(gx, (unsigned)rows);
+        if (grid.y > 65535u) return false;
+        if (out_dtype == MBNB_F16) hipLaunchKernelGGL((k_dequantize_rows8_wt<f16_t, FP8, 1>), grid, dim3(256), 0, st, q, scales, rows, cols, static_cast<f16_t *>(out));
+        else hipLaunchKernelGGL((k_dequantize_rows8_wt<bf16_t, FP8, 1>), grid, dim3(256), 0, st, q, scales, rows, cols, static_cast<bf16_t *>(out));
+    }
+    return true;
+}
+
 template <typename T, int QT, bool NESTED, int UN>
 __global__ __launch_bounds__(256) void k_dequantize_4bit_flat(const uint8_t *__restrict__ packed, AbsmaxView am, int64_t ndw, int bs_shift,
                                                              T *__restrict__ out, int write_through) {
@@ -1072,7 +1124,7 @@ int dequantize_4bit_dispatch(const uint8_t *packed, const AbsmaxView &am, int64_
 }
 
 int quantize_rowwise_dispatch(const void *, int, int64_t, int64_t, int8_t *, float *, hipStream_t);
-int dequantize_rowwise_dispatch(const int8_t *, const float *, int64_t, int64_t, int, void *, hipStream_t);
+int dequantize_rowwise_dispatch(const int8_t *, const float *, int64_t, int64_t, int, void *, hipStream_t, int store_policy = 0);
 
 int quantize_blockwise_dispatch(const void *A, int dtype, int64_t numel, int blocksize, const float *absmax_in,
                                 int8_t *out, float *absmax_out, hipStream_t st) {
@@ -1134,7 +1186,8 @@ int quantize_fp8_dispatch(const void *A, int dtype, int64_t rows, int64_t cols, 
 }
 
 int dequantize_fp8_dispatch(const uint8_t *q, const float *scales, int64_t rows, int64_t cols, int out_dtype, void *out,
-                            hipStream_t st) {
+                            hipStream_t st, int store_policy) {
+    if (launch_rows8_wt<true>(q, scales, rows, cols, out_dtype, out, st, store_policy)) return check_launch("dequantize_fp8_e4m3");
     if (cols % 16 == 0 && ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(out)) & 15) == 0 && rows * cols > 0 && rows < 65536) {
         const dim3 g16((unsigned)((cols / 16 + 255) / 256), (unsigned)rows);
         switch (out_dtype) {
@@ -1154,7 +1207,8 @@ int dequantize_fp8_dispatch(const uint8_t *q, const float *scales, int64_t rows,
 }
 
 int dequantize_rowwise_dispatch(const int8_t *q, const float *scales, int64_t rows, int64_t cols, int out_dtype,
-                                void *out, hipStream_t st) {
+                                void *out, hipStream_t st, int store_policy) {
+    if (launch_rows8_wt<false>(reinterpret_cast<const uint8_t *>(q), scales, rows, cols, out_dtype, out, st, store_policy)) return check_launch("dequantize_rowwise");
     if (cols % 16 == 0 && ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(out)) & 15) == 0 && rows * cols > 0 && rows < 65536) {
         const dim3 g16((unsigned)((cols / 16 + 255) / 256), (unsigned)rows);
         const uint8_t *qb = reinterpret_cast<const uint8_t *>(q);
