@@ -285,7 +285,9 @@ __global__ __launch_bounds__(256) void k_quantize_rowwise_masked_regs(const T *_
             hi |= (uint32_t)(uint8_t)quant_i8(unpack_lo<T>(raw[i][2 + j]), s) << (16 * j);
             hi |= (uint32_t)(uint8_t)quant_i8(unpack_hi<T>(raw[i][2 + j]), s) << (16 * j + 8);
         }
-        *reinterpret_cast<u32x2 *>(orow + (int64_t)g * 8) = u32x2{lo, hi};
+        // write-through: the int8 rows are read next by the GEMM launch, on other XCDs (tools/exp/ab_outlier.py)
+        const u32x2 pv = u32x2{lo, hi};
+        asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(orow + (int64_t)g * 8), "v"(pv) : "memory");
     }
 }
 
