@@ -1383,3 +1383,28 @@ def test_matmul_decode_beside_inside_a_graph_capture(monkeypatch):
         assert torch.equal(y, y_ref) and torch.equal(y_warm, y_ref)
         monkeypatch.setattr(bnb.functional, "DECODE_BESIDE", False)
     assert bnb.functional.in_launch_errors() == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K,dt,qt,dq", [(600, 4096, 4096, torch.bfloat16, "nf4", False),      # four dwords per thread + write-through (<= 32 Mi elements)
+                                           (2048, 2048, 2048, torch.float16, "fp4", True),        # the same, double-quantised absmax
+                                           (2100, 11008, 4096, torch.bfloat16, "nf4", True),      # > 32 Mi elements, >= 2048 rows: one dword + write-through
+                                           (700, 11008, 4096, torch.float16, "nf4", False)])      # > 32 Mi elements, < 2048 rows: the public kernel's stores
+def test_matmul_decode_once_pass_forms_keep_the_public_kernels_bits(M, N, K, dt, qt, dq):
+    """Round 3: inside matmul_4bit's decode-once path the dequantise pass runs in another shape than the public dequantize_4bit (write-through
+    stores, four dwords per thread on weights of up to 32 Mi elements: quant_kernels.hip store_policy; linear8_dense_path has the same for the
+    8-bit weights).  The scratch must hold the public kernel's bits: matmul_4bit == linear_dense(dequantize_4bit(...)) bit for bit, and
+    linear_int8 == linear_dense(dequantize_rowwise(...))."""
+    W = synthetic.normal((N, K), dt, seed=61, std=0.05).to(DEV)
+    x = synthetic.normal((M, K), dt, seed=62).to(DEV)
+    b = synthetic.normal((N,), dt, seed=63).to(DEV)
+    packed, st = bnb.quantize_4bit(W, blocksize=64, quant_type=qt, compress_statistics=dq)
+    y = bnb.matmul_4bit(x, packed, st, b)
+    assert _native.last_kernel().startswith("dequant+dense")
+    Wd = bnb.dequantize_4bit(packed, st)
+    assert torch.equal(y, bnb.functional.linear_dense(x, Wd, b))
+    del Wd
+    q, sc = bnb.quantize_rowwise(W)
+    y8 = bnb.linear_int8(x, q, sc, b)
+    assert _native.last_kernel().startswith("w8a16_dequant+dense")
+    assert torch.equal(y8, bnb.functional.linear_dense(x, bnb.dequantize_rowwise(q, sc, dt), b))
