@@ -16,8 +16,8 @@
  *     arguments) and reads no environment variables.  The only process-wide state is a
  *     mutex-protected record of which (device, kernel) pairs already had their dynamic-LDS
  *     limit raised -- an idempotent attribute set once per device, so several devices can be
- *     driven from one process or from one process each -- and, once the side-stream forms below
- *     have been used, that stream and its two events per device;
+ *     driven from one process or from one process each.  Every launch goes to the caller's `stream`;
+ *     the library owns no stream, event or device buffer;
  *   - errors are returned as an int status (0 ok, <0 argument error,
  *     >0 hipError_t); no exception crosses the ABI.  mbnb_last_error()
  *     returns a thread-local description of the last failure;
@@ -25,10 +25,14 @@
  *     pure-PyTorch code, functional.py:710-767; SURVEY.md 8b lists `_cpu` entry points as optional):
  *     every pointer is a device pointer and a call without a usable HIP device fails with the
  *     hipError_t of its first launch.  The CPU restatement of the reference lives in oracle/ and
- *     is test infrastructure only -- nothing in this library links, loads or calls it;
- *   - two entry points may enqueue work on a LIBRARY-OWNED side stream forked from / joined to
- *     `stream` by events: mbnb_matmul_4bit_sync with MBNB_MATMUL_SIDE_STREAM or
- *     MBNB_MATMUL_SPLIT_DECODE (off in the Python mirror).  Everything else touches `stream` only.
+ *     is test infrastructure only -- nothing in this library links, loads or calls it.
+ *
+ * ABI version 2 (round 4): ONE entry point per operation, as the reference has one binding per op
+ * (mm:2726-2800).  Every operation that can use scratch takes (workspace, workspace_bytes) -- NULL / 0
+ * is always valid and costs speed, never the result -- and has one `*_workspace_bytes` query; the
+ * matmuls take a `flags` word.  Version 1's mbnb_matmul_4bit_ws / _ex / _sync, the `_kw` / `_dt` /
+ * `_splitk_` queries, mbnb_linear_int8_ws / _ex, mbnb_linear_fp8_ex and mbnb_outlier_linear_ws are
+ * gone; the overlapped-decode experiments behind `_sync` live in tools/exp/parked/.
  *
  * All tensors are dense, row-major, contiguous.  All pointers are DEVICE
  * pointers on the current HIP device (the caller selects the device).
@@ -42,7 +46,7 @@
 extern "C" {
 #endif
 
-#define MBNB_ABI_VERSION 1
+#define MBNB_ABI_VERSION 2
 
 /* element dtypes */
 enum { MBNB_F16 = 0, MBNB_BF16 = 1, MBNB_F32 = 2 };
@@ -138,6 +142,11 @@ int mbnb_double_quant(const void *A, int dtype, int64_t rows, int64_t cols, int8
                       int8_t *out_row, float *col_stats, float *row_stats, int col_given,
                       int row_given, void *stream);
 
+/* flags word of mbnb_matmul_4bit / mbnb_linear_int8 / mbnb_linear_fp8 and of their workspace queries.
+ * MBNB_MATMUL_FUSED_ONLY: never dequantise the weight into the workspace -- keep the fused decode + MFMA kernels at
+ * every M (for callers that cannot spare N x K_weight x 2 bytes of scratch); the workspace then serves split-K only. */
+#define MBNB_MATMUL_FUSED_ONLY 1
+
 /* ---------------------------------------------------------------------------
  * matmul_4bit — replaces `_C.matmul_nf4` / `_C.matmul_fp4`
  * (mm:1956-2032, :2099-2151, bindings :2741-2751; call sites functional.py:743,745)
@@ -149,117 +158,48 @@ int mbnb_double_quant(const void *A, int dtype, int64_t rows, int64_t cols, int8
  *   packed  u8 [N, K_weight/2]; absmax covers [N, K_weight/blocksize]
  *   K       activation width (= QuantState.shape[1]); K_weight >= K is the padded row length
  *   bias    optional [N] of w_dtype
- * Dispatch (16-bit weights, blocksize >= 32, 16-byte aligned rows): M = 1 (and M <= 16 when
- * K % 128 != 0) -> wave-per-row GEMV (HBM-bound); 2 <= M <= 32 (<= 64 for layers of <= 16 Mi
- * weights) -> weight-streaming skinny MFMA kernel; shapes with >= 96 output tiles of 256 x 256
- * -> the 256 x 256 LDS-DMA MFMA kernel with the dequant fused into the weight-tile producer;
- * in between -> 128 x 128 MFMA tiles (split over K when mbnb_matmul_4bit_ws gets a workspace);
- * fp32 weights: with a workspace (mbnb_matmul_4bit_workspace_bytes_dt) dequantise once + f32 MFMA GEMM, else generic;
- * blocksize < 32, K % 8 != 0 -> generic kernel.
+ *   workspace  optional scratch of mbnb_matmul_4bit_workspace_bytes(...) bytes, 256-byte aligned; a shorter (or no)
+ *           workspace costs the fast path, never the result.  Nothing in it survives the call.
+ * Dispatch (16-bit weights, blocksize >= 32, 16-byte aligned rows): M = 1 -> wave-per-row GEMV (HBM-bound); 2 <= M <= 32
+ * -> weight-streaming skinny MFMA kernel; 32 < M <= 512 -> k_gemm_small (weights decoded registers -> registers, K split
+ * over f32 partials in the workspace); from 256 rows and 1.5 M outputs up, with a workspace that holds it: the weight
+ * dequantised ONCE, [N, K_weight] in the weight dtype (the bits mbnb_dequantize_4bit writes), then the dense 256 x 256 MFMA
+ * GEMM of csrc/gemm_dense.h -- the reference's own large-batch path (functional.py:753-767: dequantize_4bit, then
+ * F.linear); without one (or with MBNB_MATMUL_FUSED_ONLY): the fused decode + MFMA kernels (csrc/gemm_fused4.h, gemm256.h).
+ * f32 weights: with a workspace dequantise once + f32 MFMA GEMM (csrc/gemm_f32.hip), else the generic kernel; blocksize < 32,
+ * K % 8 != 0 -> generic kernel.
  * ------------------------------------------------------------------------- */
+int64_t mbnb_matmul_4bit_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t K_weight, int w_dtype, int flags);
 int mbnb_matmul_4bit(const void *A, int64_t M, int64_t K, const uint8_t *packed,
                      const mbnb_absmax *absmax, int64_t N, int64_t K_weight, int blocksize,
                      int quant_type, int w_dtype, const void *bias, int out_dtype, void *out,
-                     void *stream);
-
-/* matmul_4bit with a caller-provided split-K workspace.  Between the GEMV shapes (M <= 4) and the shapes that fill the
- * chip with 256 x 256 tiles, the output has too few tiles for 256 CUs; with a workspace of
- * mbnb_matmul_4bit_workspace_bytes(M, N, K) bytes (0 = not needed; 16-byte aligned) the contraction is split into K
- * slices whose f32 partial sums are added in slice order (deterministic) before the bias and the rounding.
- * Same results contract as mbnb_matmul_4bit; workspace == NULL behaves exactly like it. */
-int64_t mbnb_matmul_4bit_workspace_bytes(int64_t M, int64_t N, int64_t K);
-/* The same query for a weight whose rows are padded to K_weight > K columns (QuantState of a K that is not a multiple of
- * the blocksize; functional.py:216-223); mbnb_matmul_4bit_workspace_bytes(M, N, K) is this with K_weight = K.
- * Large M (>= 256 rows and >= 1.5 M outputs, K % 64 == 0, 16-bit weight dtype): the workspace also holds the weight dequantised ONCE,
- * [N, K_weight] in the weight dtype (256-byte aligned; the bits mbnb_dequantize_4bit writes), and the product runs as a
- * dense 256 x 256 MFMA GEMM on it (csrc/gemm_dense.h) -- the fused kernels decode every weight tile once per 256 rows of A,
- * which at M = 4096 is 16 decodes of the same weight.  The reference's own large-batch path is the same two steps
- * (functional.py:753-767, "used for M > 512": dequantize_4bit, then F.linear).  A workspace shorter than the query costs the fast path, never
- * the result. */
-int64_t mbnb_matmul_4bit_workspace_bytes_kw(int64_t M, int64_t N, int64_t K, int64_t K_weight);
-/* The query by weight dtype.  MBNB_F16 / MBNB_BF16: the one above.  MBNB_F32 (QuantState.dtype of a default nn.Linear; the
- * reference multiplies in f32, functional.py:756-773): where it beats the generic kernel (from 17 rows at 4096^2, ~100 rows
- * at 1024^2; K % 4 == 0), the weight dequantised once as f32
- * [N, K_weight] (N x K_weight x 4 bytes) for a dense f32 MFMA GEMM (csrc/gemm_f32.hip) instead of the generic kernel. */
-int64_t mbnb_matmul_4bit_workspace_bytes_dt(int64_t M, int64_t N, int64_t K, int64_t K_weight, int w_dtype);
-/* The split-K share of that query alone: a caller that cannot spare N x K_weight x 2 bytes passes a workspace of this size
- * and keeps the fused dequant + MFMA kernels at every M (0 = no split needed). */
-int64_t mbnb_matmul_4bit_splitk_workspace_bytes(int64_t M, int64_t N, int64_t K);
-int mbnb_matmul_4bit_ws(const void *A, int64_t M, int64_t K, const uint8_t *packed,
-                        const mbnb_absmax *absmax, int64_t N, int64_t K_weight, int blocksize,
-                        int quant_type, int w_dtype, const void *bias, int out_dtype, void *out,
-                        void *workspace, int64_t workspace_bytes, void *stream);
+                     void *workspace, int64_t workspace_bytes, int flags, void *stream);
 
 /* ---------------------------------------------------------------------------
  * matmul_int8 — replaces `_C.matmul_int8` (mm:1789-1834, kernel mm:155-196) /
  * functional.matmul_int8 (functional.py:788-793):
  *   out[M,N] = cast( int32(A[M,K] · B[K,N]) * (A_scales[m]/127) * (B_scales[n]/127) )
  * on the int8 MFMA.  B is read as the reference passes it, [K, N] row-major.  Large aligned problems (K % 128 == 0,
- * N % 16 == 0, 16-byte aligned A and B, >= 96 output tiles of 256 x 256) run WITHOUT a workspace: the kernel transposes
- * while it reads its LDS image (ds_read_b64_tr_b8).  With a workspace of mbnb_matmul_int8_workspace_bytes(M, N, K) (= N*K)
- * bytes, B is first re-laid out K-contiguous: for those large problems (additionally N % 64 == 0, K >= 256) that buys the
- * four-wave pipeline of csrc/gemm_dense.h on v_mfma_i32_16x16x64_i8 (transpose + GEMM 1.3-1.4 x faster than the in-place
- * kernel, same bits); smaller or unaligned problems need it for any MFMA kernel (workspace == NULL: slow generic kernel).
- * The workspace may be reused as soon as the call's work has completed on `stream`.
+ * K >= 256, N % 16 == 0, 16-byte aligned A and B, >= 96 output tiles of 256 x 256) run in ONE launch WITHOUT a workspace:
+ * the kernel transposes while it reads its LDS image (ds_read_b64_tr_b8; csrc/gemm_i8_inplace.h) and the query returns 0.
+ * Smaller or unaligned problems need mbnb_matmul_int8_workspace_bytes(M, N, K) (= N*K) bytes to re-lay B out K-contiguous
+ * for any MFMA kernel (workspace == NULL or too short: slow generic kernel).
  * ------------------------------------------------------------------------- */
 int64_t mbnb_matmul_int8_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int mbnb_matmul_int8(const int8_t *A, const int8_t *B, const float *A_scales,
                      const float *B_scales, int64_t M, int64_t N, int64_t K, int out_dtype,
-                     void *out, void *workspace, void *stream);
-
-/* mbnb_matmul_4bit_ws with a flags word.  MBNB_MATMUL_FUSED_ONLY keeps the fused dequant + MFMA kernels at every M even when
- * the workspace could hold the dequantised weight (the workspace then serves split-K only); 0 = mbnb_matmul_4bit_ws. */
-#define MBNB_MATMUL_FUSED_ONLY 1
-/* MBNB_MATMUL_FUSED4: serve large blocksize-64 problems (>= 96 tiles of 256 x 256, K % 64 == 0, K_weight % 256 == 0) with the
- * four-wave fused decode + MFMA kernel (csrc/gemm_fused4.h): one launch, no scratch, the bits of the decode-once path. */
-#define MBNB_MATMUL_FUSED4 2
-/* flags of mbnb_matmul_4bit_sync only (described there); MBNB_MATMUL_GEMM_FIRST: with MBNB_MATMUL_SIDE_STREAM, launch the gated GEMM
- * before the decoder (diagnostic). */
-#define MBNB_MATMUL_IN_WAVE 4
-#define MBNB_MATMUL_GEMM_FIRST 8
-#define MBNB_MATMUL_SIDE_STREAM 16
-#define MBNB_MATMUL_SPLIT_DECODE 32
-int mbnb_matmul_4bit_ex(const void *A, int64_t M, int64_t K, const uint8_t *packed,
-                        const mbnb_absmax *absmax, int64_t N, int64_t K_weight, int blocksize,
-                        int quant_type, int w_dtype, const void *bias, int out_dtype, void *out,
-                        void *workspace, int64_t workspace_bytes, int flags, void *stream);
-
-/* mbnb_matmul_4bit_ex with a SYNC area (the two steps of functional.py:753-767 -- dequantise, then multiply -- overlapped instead
- * of back to back; same bits as dequantize_4bit + dense GEMM).  Where mbnb_matmul_4bit_sync_bytes(...) > 0 and the workspace holds
- * the N x K_weight x 2-byte scratch:
- *   default                    csrc/gemm_beside.h: the dequantise pass as a 28-register kernel whose waves are resident BESIDE the
- *                              GEMM's, slabs of 512 k handed over through agent-scope flags (blocksize 64, plain or double-quantised
- *                              absmax with a power-of-two second blocksize, K % 512 == 0, K >= 1024, N * K_weight * 2 < 2^31, shapes
- *                              whose dense plan is unsplit 256 x 256 tiles).  Launch arrangement: one stream (decoder, then the GEMM
- *                              as an any-order launch); MBNB_MATMUL_SIDE_STREAM: decoder on a library-owned side stream forked from
- *                              / joined to `stream` by events; MBNB_MATMUL_SPLIT_DECODE: first slab in `stream`, the rest on the
- *                              side stream (joined only inside a stream capture: the GEMM cannot finish before the decoder's last
- *                              store has left).
- *   MBNB_MATMUL_IN_WAVE        csrc/gemm_dq.h: ONE launch, the GEMM's own waves decode (plain f32 absmax, 3840 < M <= 4096 rows,
- *                              K_weight == K, at most one 256 x 256 tile per compute unit of the device).
- * `sync`: mbnb_matmul_4bit_sync_bytes bytes of device memory that are ZERO on entry; the call's work leaves them zero, so one
- * buffer per (device, stream) serves every call -- it must not be shared by calls that can run concurrently.  Word
- * [tiles_n * 66] of it is an error word: non-zero afterwards = a hand-off timed out (seconds) and that call's output is not valid.
- * sync == NULL, or a shape the selected form does not serve: exactly mbnb_matmul_4bit_ex.  Neither form is faster than the two
- * launches on ROCm 7.2 / gfx950: mbnb_matmul_4bit_ex stays the default of the Python mirror. */
-int64_t mbnb_matmul_4bit_sync_bytes(int64_t M, int64_t N, int64_t K, int64_t K_weight, int blocksize);
-int mbnb_matmul_4bit_sync(const void *A, int64_t M, int64_t K, const uint8_t *packed,
-                          const mbnb_absmax *absmax, int64_t N, int64_t K_weight, int blocksize,
-                          int quant_type, int w_dtype, const void *bias, int out_dtype, void *out,
-                          void *workspace, int64_t workspace_bytes, int flags, void *sync, int64_t sync_bytes,
-                          void *stream);
+                     void *out, void *workspace, int64_t workspace_bytes, void *stream);
 
 /* The dense half of the large-M path on its own: out[M, N] = A[M, K] * W[N, ldw]^T (+ bias) for an f16 / bf16 weight that is
  * already in the compute dtype (rows ldw >= K elements apart) -- the F.linear of functional.py:767 on the tensor
- * functional.py:756 produced.  mbnb_matmul_4bit_ws calls it internally; exported for callers that keep a dequantised weight
- * (e.g. Linear4bit.dequantize(), nn/linear4bit.py:204) and for tools/.  K % 64 == 0, K >= 128, ldw % 8 == 0, A and W 16-byte
- * aligned; f32 accumulation, one rounding to `dtype`, then the cast to out_dtype.  `slices`: bits 0-7 the number of K
- * slices (> 1 splits K over slices * M * N * 4 bytes of workspace, partials added in slice order; 1 needs no workspace);
- * bits 8-15 the row extent of a tile in units of 128 rows: 0 = the library's choice, 1 = 256 (n) x 128 (m) tiles, 2 =
- * 256 x 256.  The tile shape does not change the result's bits, the slice count does.  Slice count 0 = the library's own plan
- * for this shape (what mbnb_matmul_4bit_ws / mbnb_linear_int8_ws run after their dequantise pass, so a caller that keeps the
- * dequantised weight -- Linear8bit's cache, nn/linear8bit.py:70-85 -- gets the same bits); its partials need
- * mbnb_gemm_dense_workspace_bytes(M, N, K) bytes (0 when the plan does not split), a shorter workspace means one slice.
+ * functional.py:756 produced.  mbnb_matmul_4bit calls it internally; exported for callers that keep a dequantised weight
+ * (Linear8bit's cache, nn/linear8bit.py:70-85; Linear4bit.dequantize(), nn/linear4bit.py:204) and for tools/.  K % 64 == 0,
+ * K >= 128, ldw % 8 == 0, A and W 16-byte aligned; f32 accumulation, one rounding to `dtype`, then the cast to out_dtype.
+ * `slices`: bits 0-7 the number of K slices (> 1 splits K over slices * M * N * 4 bytes of workspace, partials added in slice
+ * order; 1 needs no workspace); 0 = the library's own plan for this shape (what mbnb_matmul_4bit / mbnb_linear_int8 run after
+ * their dequantise pass, so the caller gets the same bits); its partials need mbnb_gemm_dense_workspace_bytes(M, N, K) bytes
+ * (0 when the plan does not split), a shorter workspace means one slice.  Bits 8-15: diagnostic tile selector (0 = the plan's).
+ * The tile shape does not change the result's bits, the slice count does.
  * mbnb_gemm_dense_applies: 1 when the decode-once path serves this shape (from 256 rows and 1.5 M outputs up), else 0. */
 int mbnb_gemm_dense_applies(int64_t M, int64_t N, int64_t K, int64_t ldw);
 int64_t mbnb_gemm_dense_workspace_bytes(int64_t M, int64_t N, int64_t K);
@@ -272,24 +212,15 @@ int mbnb_gemm_dense(const void *A, const void *W, int dtype, const void *bias, i
  * of Linear8bit.forward (nn/linear8bit.py:70-102):
  *   out[M,N] = X[M,K] · round_dtype(W_i8[N,K] * (scales[n]/127))^T + bias[N]
  * X, bias, out in `dtype` (f16 / bf16 / f32); f32 accumulation; one rounding.
+ * workspace: mbnb_linear_int8_workspace_bytes(M, N, K, flags) bytes (0 = not needed; 256-byte aligned): split-K partials for
+ * mid-sized M; from 256 rows and 1.5 M outputs up the weight dequantised ONCE (dequantize_rowwise's bits, [N, K] in `dtype`)
+ * followed by the dense MFMA GEMM of csrc/gemm_dense.h -- the reference's own two steps.  NULL / 0: the fused W8A16 kernels.
+ * mbnb_linear_fp8 takes the same workspace and flags.
  * ------------------------------------------------------------------------- */
+int64_t mbnb_linear_int8_workspace_bytes(int64_t M, int64_t N, int64_t K, int flags);
 int mbnb_linear_int8(const void *X, int dtype, int64_t M, int64_t K, const int8_t *W,
-                     const float *W_scales, int64_t N, const void *bias, void *out, void *stream);
-
-/* linear_int8 with a workspace of mbnb_linear_int8_workspace_bytes(M, N, K) bytes (0 = not needed; 256-byte aligned):
- * split-K partials for mid-sized M; from 256 rows and 1.5 M outputs up the weight dequantised ONCE
- * (dequantize_rowwise's bits, [N, K] in `dtype`) followed by the dense MFMA GEMM of csrc/gemm_dense.h -- the reference's own
- * two steps (nn/linear8bit.py:70-102).  workspace == NULL behaves exactly like mbnb_linear_int8.  mbnb_linear_fp8 takes the
- * same workspace. */
-int64_t mbnb_linear_int8_workspace_bytes(int64_t M, int64_t N, int64_t K);
-int mbnb_linear_int8_ws(const void *X, int dtype, int64_t M, int64_t K, const int8_t *W,
-                        const float *W_scales, int64_t N, const void *bias, void *out, void *workspace,
-                        int64_t workspace_bytes, void *stream);
-/* mbnb_linear_int8_ws with a flags word: MBNB_MATMUL_FUSED_ONLY keeps the fused W8A16 kernels at every M, whatever the
- * workspace could hold (it then serves split-K only); 0 = mbnb_linear_int8_ws. */
-int mbnb_linear_int8_ex(const void *X, int dtype, int64_t M, int64_t K, const int8_t *W,
-                        const float *W_scales, int64_t N, const void *bias, void *out, void *workspace,
-                        int64_t workspace_bytes, int flags, void *stream);
+                     const float *W_scales, int64_t N, const void *bias, void *out, void *workspace,
+                     int64_t workspace_bytes, int flags, void *stream);
 
 /* ---------------------------------------------------------------------------
  * embedding_4bit — replaces `_C.embedding_4bit_nf4` / `_C.embedding_4bit_fp4` (host mm:2309-2388, kernels
@@ -318,21 +249,17 @@ int mbnb_embedding_8bit(const int64_t *indices, int64_t n_indices, const int8_t 
  *   main   = int32(q . W_i8[N,K]^T) * (s[m]/127) * (W_scales[n]/127)  rounded to dtype  (:133-138, on the int8 MFMA;
  *            the reference multiplies dtype-rounded dequantised operands instead: <= 4e-4 (f16) / 1.3e-3 (bf16) rel.)
  *   out    = RNE(RNE(main + RNE(X[:, outlier_idx] . outlier_w^T)) + bias)               (:141-143, :110-111)
- * n_outliers may be 0 (pure INT8 path, :100-105).  `workspace` holds the int8 activations, their row scales and the
- * compact outlier activations [M, 16 * ceil(n_outliers / 16)]: mbnb_outlier_linear_workspace_bytes_n(M, K, n_outliers)
+ * n_outliers may be 0 (pure INT8 path, :100-105).  `workspace` (required) holds the int8 activations, their row scales and
+ * the compact outlier activations [M, 16 * ceil(n_outliers / 16)]: mbnb_outlier_linear_workspace_bytes(M, K, n_outliers)
  * bytes let the 256 x 256 kernels fold ANY number of outlier columns (and the bias) into their epilogue (at most 64 columns
- * on >= 96 tiles: the four-wave kernel, one 16 x 16 x 32 MFMA per output fragment and 32 columns; otherwise the eight-wave kernel, one MFMA
- * per tile and 16 columns); the two-argument query (and mbnb_outlier_linear, which assumes it) has room for 16 columns --
- * with more than that the outlier term runs as a separate pass over the output (same results).
+ * on >= 96 tiles: the four-wave kernel, one 16 x 16 x 32 MFMA per output fragment and 32 columns; otherwise the eight-wave
+ * kernel, one MFMA per tile and 16 columns).  A workspace sized for fewer columns (at least the n_outliers = 0 query) is
+ * valid: the outlier term then runs as a separate pass over the output (same results).
  * ------------------------------------------------------------------------- */
-int64_t mbnb_outlier_linear_workspace_bytes(int64_t M, int64_t K);
-int64_t mbnb_outlier_linear_workspace_bytes_n(int64_t M, int64_t K, int64_t n_outliers);
+int64_t mbnb_outlier_linear_workspace_bytes(int64_t M, int64_t K, int64_t n_outliers);
 int mbnb_outlier_linear(const void *X, int dtype, int64_t M, int64_t K, const int8_t *W, const float *W_scales,
                         int64_t N, const int64_t *outlier_idx, int64_t n_outliers, const void *outlier_w,
-                        const void *bias, void *out, void *workspace, void *stream);
-int mbnb_outlier_linear_ws(const void *X, int dtype, int64_t M, int64_t K, const int8_t *W, const float *W_scales,
-                           int64_t N, const int64_t *outlier_idx, int64_t n_outliers, const void *outlier_w,
-                           const void *bias, void *out, void *workspace, int64_t workspace_bytes, void *stream);
+                        const void *bias, void *out, void *workspace, int64_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------
  * FP8 E4M3 in the reference's own format — replaces `_C.quantize_fp8_e4m3` / `_C.dequantize_fp8_e4m3` /
@@ -342,18 +269,15 @@ int mbnb_outlier_linear_ws(const void *X, int dtype, int64_t M, int64_t K, const
  *   (exponent = floor(log2 |v|) as torch evaluates it, mantissa = trunc((|v|/2^e - 1) * 8 + 0.5) without carry,
  *   subnormals flushed to signed zero, |v| >= 256 -> 0x77, NaN -> 0x7F) — not the OCP conversion.
  *   linear_fp8: out[M,N] = X[M,K] . round_dtype(decode(W[N,K]) * scales[n])^T + bias   (LinearFP8.forward,
- *   nn/linear_fp8.py:74-103); same kernels and optional split-K workspace as mbnb_linear_int8_ws.
+ *   nn/linear_fp8.py:74-103); same kernels, workspace query and flags as mbnb_linear_int8.
  * ------------------------------------------------------------------------- */
 int mbnb_quantize_fp8_e4m3(const void *A, int dtype, int64_t rows, int64_t cols, uint8_t *out, float *scales,
                            void *stream);
 int mbnb_dequantize_fp8_e4m3(const uint8_t *q, const float *scales, int64_t rows, int64_t cols, int out_dtype,
                              void *out, void *stream);
 int mbnb_linear_fp8(const void *X, int dtype, int64_t M, int64_t K, const uint8_t *W, const float *W_scales,
-                    int64_t N, const void *bias, void *out, void *workspace, int64_t workspace_bytes, void *stream);
-/* with the flags word of mbnb_linear_int8_ex (MBNB_MATMUL_FUSED_ONLY) */
-int mbnb_linear_fp8_ex(const void *X, int dtype, int64_t M, int64_t K, const uint8_t *W, const float *W_scales,
-                       int64_t N, const void *bias, void *out, void *workspace, int64_t workspace_bytes, int flags,
-                       void *stream);
+                    int64_t N, const void *bias, void *out, void *workspace, int64_t workspace_bytes, int flags,
+                    void *stream);
 
 #ifdef __cplusplus
 }

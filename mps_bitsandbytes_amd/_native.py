@@ -18,6 +18,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmbnb_hip.so")
 
+ABI_VERSION = 2   # include/mbnb_hip.h MBNB_ABI_VERSION
 F16, BF16, F32 = 0, 1, 2
 NF4, FP4 = 0, 1
 DTYPE_CODE = {torch.float16: F16, torch.bfloat16: BF16, torch.float32: F32}
@@ -50,49 +51,30 @@ _SIGNATURES = {
     "mbnb_dequantize_rowwise": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p]),
     "mbnb_double_quant": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_int, c_int, c_void_p]),
+    "mbnb_matmul_4bit_workspace_bytes": (c_int64, [c_int64, c_int64, c_int64, c_int64, c_int, c_int]),
     "mbnb_matmul_4bit": (c_int, [c_void_p, c_int64, c_int64, c_void_p, POINTER(AbsmaxDesc), c_int64, c_int64,
-                                 c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
-    "mbnb_matmul_4bit_sync_bytes": (c_int64, [c_int64, c_int64, c_int64, c_int64, c_int]),
-    "mbnb_matmul_4bit_sync": (c_int, [c_void_p, c_int64, c_int64, c_void_p, POINTER(AbsmaxDesc), c_int64, c_int64, c_int, c_int, c_int,
-                                      c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p]),
-    "mbnb_matmul_4bit_workspace_bytes": (c_int64, [c_int64, c_int64, c_int64]),
-    "mbnb_matmul_4bit_workspace_bytes_kw": (c_int64, [c_int64, c_int64, c_int64, c_int64]),
-    "mbnb_matmul_4bit_workspace_bytes_dt": (c_int64, [c_int64, c_int64, c_int64, c_int64, c_int]),
-    "mbnb_matmul_4bit_splitk_workspace_bytes": (c_int64, [c_int64, c_int64, c_int64]),
-    "mbnb_linear_int8_workspace_bytes": (c_int64, [c_int64, c_int64, c_int64]),
+                                 c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "mbnb_matmul_int8_workspace_bytes": (c_int64, [c_int64, c_int64, c_int64]),
+    "mbnb_matmul_int8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int,
+                                 c_void_p, c_void_p, c_int64, c_void_p]),
     "mbnb_gemm_dense_applies": (c_int, [c_int64, c_int64, c_int64, c_int64]),
     "mbnb_gemm_dense_workspace_bytes": (c_int64, [c_int64, c_int64, c_int64]),
     "mbnb_gemm_dense": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p,
                         c_int64, c_int, c_void_p]),
-    "mbnb_matmul_4bit_ws": (c_int, [c_void_p, c_int64, c_int64, c_void_p, POINTER(AbsmaxDesc), c_int64, c_int64,
-                                    c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p]),
-    "mbnb_matmul_4bit_ex": (c_int, [c_void_p, c_int64, c_int64, c_void_p, POINTER(AbsmaxDesc), c_int64, c_int64,
-                                    c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
-    "mbnb_matmul_int8_workspace_bytes": (c_int64, [c_int64, c_int64, c_int64]),
-    "mbnb_matmul_int8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int,
-                                 c_void_p, c_void_p, c_void_p]),
+    "mbnb_linear_int8_workspace_bytes": (c_int64, [c_int64, c_int64, c_int64, c_int]),
     "mbnb_linear_int8": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
-                                 c_void_p, c_void_p]),
-    "mbnb_linear_int8_ws": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
-                                    c_void_p, c_void_p, c_int64, c_void_p]),
-    "mbnb_linear_int8_ex": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
-                                    c_void_p, c_void_p, c_int64, c_int, c_void_p]),
-    "mbnb_linear_fp8_ex": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
-                                   c_void_p, c_int64, c_int, c_void_p]),
+                                 c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "mbnb_quantize_fp8_e4m3": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "mbnb_dequantize_fp8_e4m3": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p]),
     "mbnb_linear_fp8": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
-                                c_void_p, c_int64, c_void_p]),
+                                c_void_p, c_int64, c_int, c_void_p]),
     "mbnb_embedding_4bit": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int,
                                     c_int64, c_int, c_void_p, c_void_p]),
     "mbnb_embedding_8bit": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int64, c_int,
                                     c_void_p, c_void_p]),
-    "mbnb_outlier_linear_workspace_bytes": (c_int64, [c_int64, c_int64]),
-    "mbnb_outlier_linear_workspace_bytes_n": (c_int64, [c_int64, c_int64, c_int64]),
-    "mbnb_outlier_linear_ws": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
-                                       c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "mbnb_outlier_linear_workspace_bytes": (c_int64, [c_int64, c_int64, c_int64]),
     "mbnb_outlier_linear": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
-                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
@@ -125,8 +107,8 @@ def lib():
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        if handle.mbnb_abi_version() != 1:
-            raise OSError(f"ABI version mismatch: library reports {handle.mbnb_abi_version()}, binding expects 1")
+        if handle.mbnb_abi_version() != ABI_VERSION:
+            raise OSError(f"ABI version mismatch: library reports {handle.mbnb_abi_version()}, binding expects {ABI_VERSION}")
     except (OSError, AttributeError) as e:
         _load_error = f"mps_bitsandbytes_amd: cannot load {LIB_PATH}: {e}"
         raise RuntimeError(_load_error) from e

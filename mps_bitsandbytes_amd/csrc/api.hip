@@ -75,12 +75,6 @@ int64_t gemm_small_workspace_bytes(int64_t, int64_t, int64_t, int64_t);
 int64_t gemm_small8_workspace_bytes(int64_t, int64_t, int64_t);
 int64_t gemm_f32_workspace_bytes(int64_t, int64_t, int64_t, int64_t);
 int64_t gemm_dense_workspace_bytes(int64_t, int64_t, int64_t, int64_t);
-int64_t gemm_dq_sync_bytes(int64_t, int64_t, int64_t, int64_t, int);
-int matmul_4bit_dq_path(const void *, int64_t, int64_t, const uint8_t *, const AbsmaxView &, int64_t, int64_t, int, int, int, const void *, int, void *,
-                        void *, int64_t, void *, int64_t, hipStream_t);
-int64_t gemm_beside_sync_bytes(int64_t, int64_t, int64_t, int64_t, int);
-int matmul_4bit_beside_path(const void *, int64_t, int64_t, const uint8_t *, const AbsmaxView &, int64_t, int64_t, int, int, int, const void *, int, void *,
-                            void *, int64_t, void *, int64_t, hipStream_t, int);
 bool gemm_dense_shape(int64_t, int64_t, int64_t, int64_t);
 int64_t gemm_dense_slices(int64_t, int64_t, int64_t);
 int gemm_dense_direct(const void *, const void *, int, const void *, int, void *, int64_t, int64_t, int64_t, int64_t, float *, int64_t, int,
@@ -235,10 +229,10 @@ int mbnb_double_quant(const void *A, int dtype, int64_t rows, int64_t cols, int8
                                  static_cast<hipStream_t>(stream));
 }
 
-int mbnb_matmul_4bit_ex(const void *A, int64_t M, int64_t K, const uint8_t *packed, const mbnb_absmax *absmax, int64_t N,
-                        int64_t K_weight, int blocksize, int quant_type, int w_dtype, const void *bias, int out_dtype,
-                        void *out, void *workspace, int64_t workspace_bytes, int flags, void *stream) {
-    if (flags & ~(MBNB_MATMUL_FUSED_ONLY | MBNB_MATMUL_FUSED4)) return fail(MBNB_ERR_ARG, "matmul_4bit: unknown flags 0x%x", flags);
+int mbnb_matmul_4bit(const void *A, int64_t M, int64_t K, const uint8_t *packed, const mbnb_absmax *absmax, int64_t N,
+                     int64_t K_weight, int blocksize, int quant_type, int w_dtype, const void *bias, int out_dtype,
+                     void *out, void *workspace, int64_t workspace_bytes, int flags, void *stream) {
+    if (flags & ~MBNB_MATMUL_FUSED_ONLY) return fail(MBNB_ERR_ARG, "matmul_4bit: unknown flags 0x%x", flags);
     if (!dtype_ok(w_dtype) || !dtype_ok(out_dtype) || !qt_ok(quant_type))
         return fail(MBNB_ERR_ARG, "matmul_4bit: bad dtype/quant_type");
     if (M < 0 || N < 0 || K < 0) return fail(MBNB_ERR_ARG, "matmul_4bit: negative size");
@@ -246,92 +240,45 @@ int mbnb_matmul_4bit_ex(const void *A, int64_t M, int64_t K, const uint8_t *pack
     if (K_weight < K || K_weight % blocksize || K_weight % 2)
         return fail(MBNB_ERR_SHAPE, "matmul_4bit: K_weight=%lld inconsistent with K=%lld blocksize=%d",
                     (long long)K_weight, (long long)K, blocksize);
+    if (workspace_bytes < 0) return fail(MBNB_ERR_ARG, "matmul_4bit: negative workspace size");
     if (M == 0 || N == 0) return MBNB_OK;
     AbsmaxView v;
     if (int rc = absmax_view(absmax, "matmul_4bit", v)) return rc;
     if (!A || !packed || !out) return fail(MBNB_ERR_ARG, "matmul_4bit: NULL pointer");
-    // the split-K workspace travels down the dispatch as an argument (no per-call state is kept anywhere)
+    // the workspace travels down the dispatch as an argument (no per-call state is kept anywhere)
     return matmul_4bit_dispatch(A, M, K, packed, v, N, K_weight, blocksize, quant_type, w_dtype, bias, out_dtype, out,
                                 workspace, workspace ? workspace_bytes : 0, flags, static_cast<hipStream_t>(stream));
 }
 
-int64_t mbnb_matmul_4bit_sync_bytes(int64_t M, int64_t N, int64_t K, int64_t K_weight, int blocksize) {
-    if (M <= 0 || N <= 0 || K <= 0) return 0;
-    const int64_t a = gemm_dq_sync_bytes(M, N, K, K_weight, blocksize), b = gemm_beside_sync_bytes(M, N, K, K_weight, blocksize);
-    return a > b ? a : b;
-}
-
-int mbnb_matmul_4bit_sync(const void *A, int64_t M, int64_t K, const uint8_t *packed, const mbnb_absmax *absmax, int64_t N,
-                          int64_t K_weight, int blocksize, int quant_type, int w_dtype, const void *bias, int out_dtype,
-                          void *out, void *workspace, int64_t workspace_bytes, int flags, void *sync, int64_t sync_bytes, void *stream) {
-    if (sync != nullptr && workspace != nullptr && !(flags & (MBNB_MATMUL_FUSED_ONLY | MBNB_MATMUL_FUSED4)) && dtype_ok(w_dtype) &&
-        dtype_ok(out_dtype) && qt_ok(quant_type) && absmax != nullptr && A && packed && out && M > 0 && N > 0 && K > 0 &&
-        pow2(blocksize) && K_weight >= K) {
-        AbsmaxView v;
-        if (int rc = absmax_view(absmax, "matmul_4bit", v)) return rc;
-        int rc = MBNB_NOT_APPLICABLE;
-        if (!(flags & MBNB_MATMUL_IN_WAVE))
-            rc = matmul_4bit_beside_path(A, M, K, packed, v, N, K_weight, blocksize, quant_type, w_dtype, bias, out_dtype, out, workspace,
-                                         workspace_bytes, sync, sync_bytes, static_cast<hipStream_t>(stream), ((flags & MBNB_MATMUL_SPLIT_DECODE) ? 4 : 0) | ((flags & MBNB_MATMUL_SIDE_STREAM) ? 2 : 0) | ((flags & MBNB_MATMUL_GEMM_FIRST) ? 1 : 0));
-        else
-            rc = matmul_4bit_dq_path(A, M, K, packed, v, N, K_weight, blocksize, quant_type, w_dtype, bias, out_dtype, out, workspace,
-                                     workspace_bytes, sync, sync_bytes, static_cast<hipStream_t>(stream));
-        if (rc != MBNB_NOT_APPLICABLE) return rc;
-    }
-    flags &= ~(MBNB_MATMUL_IN_WAVE | MBNB_MATMUL_GEMM_FIRST | MBNB_MATMUL_SIDE_STREAM | MBNB_MATMUL_SPLIT_DECODE);
-    return mbnb_matmul_4bit_ex(A, M, K, packed, absmax, N, K_weight, blocksize, quant_type, w_dtype, bias, out_dtype, out, workspace,
-                               workspace_bytes, flags, stream);
-}
-
-int mbnb_matmul_4bit_ws(const void *A, int64_t M, int64_t K, const uint8_t *packed, const mbnb_absmax *absmax, int64_t N,
-                        int64_t K_weight, int blocksize, int quant_type, int w_dtype, const void *bias, int out_dtype,
-                        void *out, void *workspace, int64_t workspace_bytes, void *stream) {
-    return mbnb_matmul_4bit_ex(A, M, K, packed, absmax, N, K_weight, blocksize, quant_type, w_dtype, bias, out_dtype, out,
-                               workspace, workspace_bytes, 0, stream);
-}
-
-int mbnb_matmul_4bit(const void *A, int64_t M, int64_t K, const uint8_t *packed, const mbnb_absmax *absmax, int64_t N,
-                     int64_t K_weight, int blocksize, int quant_type, int w_dtype, const void *bias, int out_dtype,
-                     void *out, void *stream) {
-    return mbnb_matmul_4bit_ws(A, M, K, packed, absmax, N, K_weight, blocksize, quant_type, w_dtype, bias, out_dtype, out,
-                               nullptr, 0, stream);
-}
-
-int64_t mbnb_matmul_4bit_splitk_workspace_bytes(int64_t M, int64_t N, int64_t K) {
-    if (M <= 0 || N <= 0 || K <= 0) return 0;
+// the split-K share of the query: slices x tiles x 128 x 128 f32 (128 x 128 kernel) / slices x M x N f32 (k_gemm_mid, k_gemm_small)
+static int64_t matmul4_splitk_workspace_bytes(int64_t M, int64_t N, int64_t K) {
     const int64_t s = matmul4_splitk_slices(M, N, K);
-    const int64_t a = s > 1 ? s * ((M + 127) / 128) * ((N + 127) / 128) * 65536 : 0;   // slices x tiles x 128 x 128 f32
-    const int64_t b = gemm_mid_workspace_bytes(M, N, K);   // slices x M x N f32 (mid-sized batches, blocksize 64)
-    const int64_t c = gemm_small_workspace_bytes(M, N, K, K);   // slices x M x N f32 (64 < M <= 256, blocksize 64)
+    const int64_t a = s > 1 ? s * ((M + 127) / 128) * ((N + 127) / 128) * 65536 : 0;
+    const int64_t b = gemm_mid_workspace_bytes(M, N, K);
+    const int64_t c = gemm_small_workspace_bytes(M, N, K, K);
     const int64_t ab = a > b ? a : b;
     return ab > c ? ab : c;
 }
 
-int64_t mbnb_matmul_4bit_workspace_bytes_kw(int64_t M, int64_t N, int64_t K, int64_t K_weight) {
-    if (M <= 0 || N <= 0 || K <= 0 || K_weight < K) return 0;
-    const int64_t ab = mbnb_matmul_4bit_splitk_workspace_bytes(M, N, K);
+int64_t mbnb_matmul_4bit_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t K_weight, int w_dtype, int flags) {
+    if (M <= 0 || N <= 0 || K <= 0 || K_weight < K || !dtype_ok(w_dtype)) return 0;
+    const bool fused_only = (flags & MBNB_MATMUL_FUSED_ONLY) != 0;
+    if (w_dtype == MBNB_F32) return fused_only ? 0 : gemm_f32_workspace_bytes(M, N, K, K_weight);
+    const int64_t ab = matmul4_splitk_workspace_bytes(M, N, K);
+    if (fused_only) return ab;
     const int64_t c = gemm_dense_workspace_bytes(M, N, K, K_weight);   // the dequantised weight (+ split-K partials): large M
     return ab > c ? ab : c;
 }
 
-int64_t mbnb_matmul_4bit_workspace_bytes_dt(int64_t M, int64_t N, int64_t K, int64_t K_weight, int w_dtype) {
-    if (w_dtype != MBNB_F32) return mbnb_matmul_4bit_workspace_bytes_kw(M, N, K, K_weight);
-    if (M <= 0 || N <= 0 || K <= 0 || K_weight < K) return 0;
-    return gemm_f32_workspace_bytes(M, N, K, K_weight);
-}
-
-int64_t mbnb_matmul_4bit_workspace_bytes(int64_t M, int64_t N, int64_t K) {
-    return mbnb_matmul_4bit_workspace_bytes_kw(M, N, K, K);
-}
-
-int64_t mbnb_linear_int8_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+int64_t mbnb_linear_int8_workspace_bytes(int64_t M, int64_t N, int64_t K, int flags) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     const int64_t s = matmul4_splitk_slices(M, N, K);
     const int64_t a = s > 1 ? s * ((M + 127) / 128) * ((N + 127) / 128) * 65536 : 0;   // slices x tiles x 128 x 128 f32
-    const int64_t c = gemm_dense_workspace_bytes(M, N, K, K);   // large M: the dequantised weight (+ split-K partials)
     const int64_t d = gemm_small8_workspace_bytes(M, N, K);   // 32 < M <= 384: slices x M x N f32 (gemm_small8.h)
-    const int64_t ac = a > c ? a : c;
-    return ac > d ? ac : d;
+    const int64_t ad = a > d ? a : d;
+    if (flags & MBNB_MATMUL_FUSED_ONLY) return ad;
+    const int64_t c = gemm_dense_workspace_bytes(M, N, K, K);   // large M: the dequantised weight (+ split-K partials)
+    return ad > c ? ad : c;
 }
 
 int mbnb_gemm_dense(const void *A, const void *W, int dtype, const void *bias, int out_dtype, void *out, int64_t M, int64_t N,
@@ -373,34 +320,25 @@ int64_t mbnb_matmul_int8_workspace_bytes(int64_t M, int64_t N, int64_t K) {
 }
 
 int mbnb_matmul_int8(const int8_t *A, const int8_t *B, const float *A_scales, const float *B_scales, int64_t M,
-                     int64_t N, int64_t K, int out_dtype, void *out, void *workspace, void *stream) {
+                     int64_t N, int64_t K, int out_dtype, void *out, void *workspace, int64_t workspace_bytes, void *stream) {
     if (!dtype_ok(out_dtype)) return fail(MBNB_ERR_ARG, "matmul_int8: bad dtype");
     if (M < 0 || N < 0 || K < 0) return fail(MBNB_ERR_ARG, "matmul_int8: negative size");
     if (M == 0 || N == 0) return MBNB_OK;
     if (!A || !B || !A_scales || !B_scales || !out) return fail(MBNB_ERR_ARG, "matmul_int8: NULL pointer");
+    if (workspace != nullptr && workspace_bytes < N * K) workspace = nullptr;   // a short workspace costs the fast path, never the result
     return matmul_int8_dispatch(A, B, A_scales, B_scales, M, N, K, out_dtype, out, workspace,
                                 static_cast<hipStream_t>(stream));
 }
 
-int mbnb_linear_int8_ex(const void *X, int dtype, int64_t M, int64_t K, const int8_t *W, const float *W_scales, int64_t N,
-                        const void *bias, void *out, void *workspace, int64_t workspace_bytes, int flags, void *stream) {
+int mbnb_linear_int8(const void *X, int dtype, int64_t M, int64_t K, const int8_t *W, const float *W_scales, int64_t N,
+                     const void *bias, void *out, void *workspace, int64_t workspace_bytes, int flags, void *stream) {
     if (flags & ~MBNB_MATMUL_FUSED_ONLY) return fail(MBNB_ERR_ARG, "linear_int8: unknown flags 0x%x", flags);
     if (!dtype_ok(dtype)) return fail(MBNB_ERR_ARG, "linear_int8: bad dtype");
-    if (M < 0 || N < 0 || K < 0) return fail(MBNB_ERR_ARG, "linear_int8: negative size");
+    if (M < 0 || N < 0 || K < 0 || workspace_bytes < 0) return fail(MBNB_ERR_ARG, "linear_int8: negative size");
     if (M == 0 || N == 0) return MBNB_OK;
     if (!X || !W || !W_scales || !out) return fail(MBNB_ERR_ARG, "linear_int8: NULL pointer");
     return linear_int8_dispatch(X, dtype, M, K, W, W_scales, N, bias, out, workspace, workspace ? workspace_bytes : 0,
                                 (flags & MBNB_MATMUL_FUSED_ONLY) != 0, static_cast<hipStream_t>(stream));
-}
-
-int mbnb_linear_int8_ws(const void *X, int dtype, int64_t M, int64_t K, const int8_t *W, const float *W_scales, int64_t N,
-                        const void *bias, void *out, void *workspace, int64_t workspace_bytes, void *stream) {
-    return mbnb_linear_int8_ex(X, dtype, M, K, W, W_scales, N, bias, out, workspace, workspace_bytes, 0, stream);
-}
-
-int mbnb_linear_int8(const void *X, int dtype, int64_t M, int64_t K, const int8_t *W, const float *W_scales, int64_t N,
-                     const void *bias, void *out, void *stream) {
-    return mbnb_linear_int8_ws(X, dtype, M, K, W, W_scales, N, bias, out, nullptr, 0, stream);
 }
 
 int mbnb_embedding_4bit(const int64_t *indices, int64_t n_indices, const uint8_t *weight_packed, const float *weight_absmax,
@@ -429,18 +367,14 @@ int mbnb_embedding_8bit(const int64_t *indices, int64_t n_indices, const int8_t 
                                    has_padding, padding_idx, out_dtype, out, static_cast<hipStream_t>(stream));
 }
 
-int64_t mbnb_outlier_linear_workspace_bytes(int64_t M, int64_t K) {
-    if (M < 0 || K < 0) return 0;
-    return outlier_linear_workspace_bytes(M, K, 16);     // room for one chunk of 16 outlier columns in the fused epilogue
-}
-int64_t mbnb_outlier_linear_workspace_bytes_n(int64_t M, int64_t K, int64_t n_outliers) {
+int64_t mbnb_outlier_linear_workspace_bytes(int64_t M, int64_t K, int64_t n_outliers) {
     if (M < 0 || K < 0 || n_outliers < 0) return 0;
-    return outlier_linear_workspace_bytes(M, K, n_outliers > 16 ? n_outliers : 16);
+    return outlier_linear_workspace_bytes(M, K, n_outliers > 16 ? n_outliers : 16);   // room for at least one chunk of 16 columns
 }
 
-int mbnb_outlier_linear_ws(const void *X, int dtype, int64_t M, int64_t K, const int8_t *W, const float *W_scales, int64_t N,
-                           const int64_t *outlier_idx, int64_t n_outliers, const void *outlier_w, const void *bias, void *out,
-                           void *workspace, int64_t workspace_bytes, void *stream) {
+int mbnb_outlier_linear(const void *X, int dtype, int64_t M, int64_t K, const int8_t *W, const float *W_scales, int64_t N,
+                        const int64_t *outlier_idx, int64_t n_outliers, const void *outlier_w, const void *bias, void *out,
+                        void *workspace, int64_t workspace_bytes, void *stream) {
     if (!dtype_ok(dtype)) return fail(MBNB_ERR_ARG, "outlier_linear: bad dtype");
     if (M < 0 || N < 0 || K <= 0 || n_outliers < 0) return fail(MBNB_ERR_ARG, "outlier_linear: bad size");
     if (M == 0 || N == 0) return MBNB_OK;
@@ -452,15 +386,6 @@ int mbnb_outlier_linear_ws(const void *X, int dtype, int64_t M, int64_t K, const
     return outlier_linear_dispatch(X, dtype, M, K, W, W_scales, N, outlier_idx, n_outliers, outlier_w, bias, out, workspace,
                                    workspace_bytes, static_cast<hipStream_t>(stream));
 }
-
-int mbnb_outlier_linear(const void *X, int dtype, int64_t M, int64_t K, const int8_t *W, const float *W_scales, int64_t N,
-                        const int64_t *outlier_idx, int64_t n_outliers, const void *outlier_w, const void *bias, void *out,
-                        void *workspace, void *stream) {
-    // workspace sized by mbnb_outlier_linear_workspace_bytes(M, K): the fused epilogue serves up to 16 outlier columns
-    return mbnb_outlier_linear_ws(X, dtype, M, K, W, W_scales, N, outlier_idx, n_outliers, outlier_w, bias, out, workspace,
-                                  M >= 0 && K >= 0 ? outlier_linear_workspace_bytes(M, K, 16) : 0, stream);
-}
-
 
 int mbnb_quantize_fp8_e4m3(const void *A, int dtype, int64_t rows, int64_t cols, uint8_t *out, float *scales, void *stream) {
     if (!dtype_ok(dtype)) return fail(MBNB_ERR_ARG, "quantize_fp8_e4m3: bad dtype");
@@ -479,20 +404,15 @@ int mbnb_dequantize_fp8_e4m3(const uint8_t *q, const float *scales, int64_t rows
     return dequantize_fp8_dispatch(q, scales, rows, cols, out_dtype, out, static_cast<hipStream_t>(stream));
 }
 
-int mbnb_linear_fp8_ex(const void *X, int dtype, int64_t M, int64_t K, const uint8_t *W, const float *W_scales, int64_t N,
-                       const void *bias, void *out, void *workspace, int64_t workspace_bytes, int flags, void *stream) {
+int mbnb_linear_fp8(const void *X, int dtype, int64_t M, int64_t K, const uint8_t *W, const float *W_scales, int64_t N,
+                    const void *bias, void *out, void *workspace, int64_t workspace_bytes, int flags, void *stream) {
     if (flags & ~MBNB_MATMUL_FUSED_ONLY) return fail(MBNB_ERR_ARG, "linear_fp8: unknown flags 0x%x", flags);
     if (!dtype_ok(dtype)) return fail(MBNB_ERR_ARG, "linear_fp8: bad dtype");
-    if (M < 0 || N < 0 || K < 0) return fail(MBNB_ERR_ARG, "linear_fp8: negative size");
+    if (M < 0 || N < 0 || K < 0 || workspace_bytes < 0) return fail(MBNB_ERR_ARG, "linear_fp8: negative size");
     if (M == 0 || N == 0) return MBNB_OK;
     if (!X || !W || !W_scales || !out) return fail(MBNB_ERR_ARG, "linear_fp8: NULL pointer");
     return linear_fp8_dispatch(X, dtype, M, K, W, W_scales, N, bias, out, workspace, workspace ? workspace_bytes : 0,
                                (flags & MBNB_MATMUL_FUSED_ONLY) != 0, static_cast<hipStream_t>(stream));
-}
-
-int mbnb_linear_fp8(const void *X, int dtype, int64_t M, int64_t K, const uint8_t *W, const float *W_scales, int64_t N,
-                    const void *bias, void *out, void *workspace, int64_t workspace_bytes, void *stream) {
-    return mbnb_linear_fp8_ex(X, dtype, M, K, W, W_scales, N, bias, out, workspace, workspace_bytes, 0, stream);
 }
 
 }  // extern "C"

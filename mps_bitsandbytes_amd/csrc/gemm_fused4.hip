@@ -50,7 +50,7 @@ int matmul_4bit_fused4_path(const void *A, int64_t M, int64_t K, const uint8_t *
         else MBNB_F4(bf16_t, false);
     }
 #undef MBNB_F4
-    set_kernel_name("fused4");
+    set_kernel_name("mfma256f");
     return rc;
 }
 

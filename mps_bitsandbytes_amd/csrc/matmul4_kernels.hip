@@ -21,11 +21,6 @@
 
 namespace mbnb {
 
-// shipping 256 x 256 kernel for blocksize 64 (gemm256s.h), compiled in gemm256s.hip
-template <typename T, bool NESTED>
-int launch_gemm256s(const T *x, const typename Q4ProducerRT<T, NESTED>::Params &wp, const T *bias, void *out, int out_dtype,
-                    int64_t M, int64_t N, int64_t K, hipStream_t st);
-
 // mid-sized batches (gemm_mid.h), compiled in gemm_mid.hip
 template <typename T, typename OutT, bool NESTED, int ABL = 0>
 int launch_gemm_mid(const T *x, const typename Q4ProducerRT<T, NESTED>::Params &wp, const T *bias, OutT *out, int64_t M,
@@ -405,9 +400,12 @@ static int launch_matmul4(const void *A, int64_t M, int64_t K, const uint8_t *pa
                 constexpr bool use_p = false;
 #endif
                 if (am4 && !use_p) {
-                    // blocksize 64: k_gemm256s (absmax-by-4, byte table, packed weights two k-steps per fetch)
-                    set_kernel_name("mfma256");
-                    return launch_gemm256s<T, NESTED>(x, wp, b, static_cast<void *>(o), od, M, N, K, st);
+                    // blocksize 64: k_gemm_fused4 (gemm_fused4.h: the decode inside the four-wave MFMA pipeline; the no-scratch kernel since
+                    // round 4 -- 117.5 us against 120.3 for the eight-wave k_gemm256s at 4096^3, tools/exp/parked/); what it does not take
+                    // (unaligned packed bytes / absmax) stays on k_gemm256p below
+                    const int rc4 = matmul_4bit_fused4_path(A, M, K, packed, am, N, K_weight, blocksize, QT, std::is_same<T, f16_t>::value ? MBNB_F16 : MBNB_BF16,
+                                                            bias, od, out, st);
+                    if (rc4 != MBNB_NOT_APPLICABLE) return rc4;
                 }
 #ifdef MBNB_ABLATION
                 // diagnostic builds: the measured schedule alternatives
@@ -518,10 +516,6 @@ int matmul_4bit_dispatch(const void *A, int64_t M, int64_t K, const uint8_t *pac
                          int64_t K_weight, int blocksize, int qt, int w_dtype, const void *bias, int out_dtype,
                          void *out, void *workspace, int64_t ws_bytes, int flags, hipStream_t st) {
     const bool fused_only = (flags & MBNB_MATMUL_FUSED_ONLY) != 0;
-    if (flags & MBNB_MATMUL_FUSED4) {   // the four-wave fused kernel (gemm_fused4.hip) where it applies
-        const int rc = matmul_4bit_fused4_path(A, M, K, packed, am, N, K_weight, blocksize, qt, w_dtype, bias, out_dtype, out, st);
-        if (rc != MBNB_NOT_APPLICABLE) return rc;
-    }
     // 256 < M <= 512 rows that k_gemm_small serves in one round of workgroups stay fused (gemm_small.hip: gemm_small_one_round); the
     // conditions of that branch of launch_matmul4 are repeated here so that nothing else is kept away from the decode-once path
     const bool small_first = (w_dtype == MBNB_F16 || w_dtype == MBNB_BF16) && blocksize >= 32 && (K_weight % 32 == 0) && (K % 8 == 0) &&

@@ -68,51 +68,7 @@ _warned: set = set()
 # linear_int8 and matmul_fp8_e4m3 alike (the FUSED_ONLY flag travels to all three entry points).  The scratch is transient:
 # N x K_weight x 2 bytes per call from torch's caching allocator (32 MB for a 4096^2 layer, ~1 GB for a 128k x 4096 head).
 DECODE_ONCE = True
-# Large M (3840 < M <= 4096 rows, blocksize 64, plain absmax, one tile per compute unit): decode the weight once INSIDE the GEMM
-# launch instead of in a launch of its own (csrc/gemm_dq.h; same bits).  OFF by default: at 4096^3 the one-launch form measures
-# 106-107 us against 105 us for the two launches (profiles/r03_dq_ablation.txt: the hand-off's write-through stores, agent-scope
-# atomics and the 3.6 us start-up eat what the hidden dequantise pass saves), and it needs every workgroup resident at once.
-DECODE_IN_LAUNCH = False
-# Large M, blocksize 64, K % 512 == 0: the dequantise pass as a 28-register kernel whose waves run BESIDE the GEMM's on the same SIMDs,
-# slabs handed over through flags (csrc/gemm_beside.h; same bits).  OFF by default: the kernels overlap as intended, but starting two
-# kernels concurrently costs more than the pass on this runtime (a dependency between two queues ~8 us, the any-order launch flag
-# not honoured on gfx9): 105-115 us against 100-104 for the two launches (profiles/r03_beside_ab.txt).
-# BESIDE_SIDE_STREAM / BESIDE_SPLIT / BESIDE_GEMM_FIRST pick the launch arrangement (flags of mbnb_matmul_4bit_sync).
-DECODE_BESIDE = False
-BESIDE_SIDE_STREAM = False
-BESIDE_SPLIT = False
-BESIDE_GEMM_FIRST = False
-MATMUL_IN_WAVE = 4
-MATMUL_GEMM_FIRST = 8
-MATMUL_SIDE_STREAM = 16
-MATMUL_SPLIT_DECODE = 32
-_SYNC_AREAS: dict = {}
-
-
-def _sync_area(device, M, N, K, K_weight, blocksize):
-    """The zeroed hand-off area of the in-launch decode path for this (device, stream), or None where the path does not apply.
-    The kernel leaves it zeroed, so it is allocated and cleared once."""
-    need = int(_native.lib().mbnb_matmul_4bit_sync_bytes(M, N, K, K_weight, int(blocksize)))
-    if need <= 0:
-        return None
-    key = (device.index if device.index is not None else torch.cuda.current_device(), int(torch.cuda.current_stream(device).cuda_stream))
-    buf = _SYNC_AREAS.get(key)
-    if buf is None or buf.numel() < need:
-        buf = torch.zeros(max(need, 32768), dtype=torch.uint8, device=device)
-        _SYNC_AREAS[key] = buf
-    return buf
-
-
-def in_launch_errors() -> int:
-    """Non-zero words of the in-launch path's sync areas (synchronises): 0 = every hand-off of every call so far went through and
-    every flag is back to zero.  A timed-out hand-off (a workgroup not resident for seconds) leaves its error word set."""
-    bad = 0
-    for buf in _SYNC_AREAS.values():
-        bad += int((buf != 0).sum().item())
-    return bad
-
-
-MATMUL_FUSED_ONLY = 1   # include/mbnb_hip.h MBNB_MATMUL_FUSED_ONLY: the flags word of mbnb_matmul_4bit_ex / mbnb_linear_int8_ex / mbnb_linear_fp8_ex
+MATMUL_FUSED_ONLY = 1   # include/mbnb_hip.h MBNB_MATMUL_FUSED_ONLY: the flags word of mbnb_matmul_4bit / mbnb_linear_int8 / mbnb_linear_fp8
 
 
 def _warn_once(key: str, message: str) -> None:
@@ -607,33 +563,14 @@ def matmul_4bit(
     # K is split over f32 partials; large M (>= 256 rows, >= 1.5 M outputs) decodes the weight ONCE into it (N x K_weight in the weight dtype) and
     # runs a dense MFMA GEMM instead of re-decoding every weight tile per 256 rows.  torch's caching allocator makes the
     # allocation a pointer bump; the memory goes back to the pool on return.
-    if DECODE_ONCE:
-        ws_bytes = int(_native.lib().mbnb_matmul_4bit_workspace_bytes_dt(M, N, K, K_weight, w_code))
-    else:
-        ws_bytes = int(_native.lib().mbnb_matmul_4bit_splitk_workspace_bytes(M, N, K))
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=A.device) if ws_bytes > 0 else None
     flags = 0 if DECODE_ONCE else MATMUL_FUSED_ONLY
-    # Where the shape allows it the weight is decoded once INSIDE the GEMM launch (csrc/gemm_dq.h): the launch needs a small
-    # sync area that is zero on entry and that it leaves zero -- one persistent buffer per (device, stream), made on first use.
-    # DECODE_BESIDE: the dequantise pass as a 32-register kernel on a side stream, resident beside the GEMM's waves (csrc/gemm_beside.h).
-    sync = None
-    if DECODE_ONCE and ws is not None and (DECODE_BESIDE or (DECODE_IN_LAUNCH and quant_state.state2 is None)):
-        sync = _sync_area(A.device, M, N, K, K_weight, blocksize)
-        if sync is not None and not DECODE_BESIDE:
-            flags |= MATMUL_IN_WAVE
-        elif sync is not None:
-            flags |= (MATMUL_SPLIT_DECODE if BESIDE_SPLIT else 0) | (MATMUL_SIDE_STREAM if BESIDE_SIDE_STREAM else 0) | (MATMUL_GEMM_FIRST | MATMUL_SIDE_STREAM if BESIDE_GEMM_FIRST else 0)
+    ws_bytes = int(_native.lib().mbnb_matmul_4bit_workspace_bytes(M, N, K, K_weight, w_code, flags))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=A.device) if ws_bytes > 0 else None
     with torch.cuda.device(A.device):
-        if sync is not None:
-            check(_native.lib().mbnb_matmul_4bit_sync(
-                ptr(A2), M, K, ptr(packed), ctypes.byref(desc), N, K_weight, int(blocksize),
-                _native.QUANT_CODE[quant_state.quant_type], w_code, ptr(bias_w), _native.DTYPE_CODE[out_dtype],
-                ptr(out), ptr(ws), ws_bytes, flags, ptr(sync), sync.numel(), stream_ptr(A.device)), "matmul_4bit")
-        else:
-            check(_native.lib().mbnb_matmul_4bit_ex(
-                ptr(A2), M, K, ptr(packed), ctypes.byref(desc), N, K_weight, int(blocksize),
-                _native.QUANT_CODE[quant_state.quant_type], w_code, ptr(bias_w), _native.DTYPE_CODE[out_dtype],
-                ptr(out), ptr(ws), ws_bytes, flags, stream_ptr(A.device)), "matmul_4bit")
+        check(_native.lib().mbnb_matmul_4bit(
+            ptr(A2), M, K, ptr(packed), ctypes.byref(desc), N, K_weight, int(blocksize),
+            _native.QUANT_CODE[quant_state.quant_type], w_code, ptr(bias_w), _native.DTYPE_CODE[out_dtype],
+            ptr(out), ptr(ws), ws_bytes, flags, stream_ptr(A.device)), "matmul_4bit")
     if out_dtype != compute_dtype:
         out = out.to(compute_dtype)
     return out.reshape(*orig_shape[:-1], N)
@@ -683,7 +620,7 @@ def matmul_int8(A: Tensor, B: Tensor, A_scales: Tensor, B_scales: Tensor,
     workspace = torch.empty(ws_bytes, dtype=torch.int8, device=A.device) if ws_bytes > 0 else None
     with torch.cuda.device(A.device):
         check(_native.lib().mbnb_matmul_int8(
-            ptr(A), ptr(B), ptr(sa), ptr(sb), M, N, K, _native.DTYPE_CODE[out_dtype], ptr(out), ptr(workspace),
+            ptr(A), ptr(B), ptr(sa), ptr(sb), M, N, K, _native.DTYPE_CODE[out_dtype], ptr(out), ptr(workspace), ws_bytes,
             stream_ptr(A.device)), "matmul_int8")
     return out if out_dtype == dtype else out.to(dtype)
 
@@ -709,11 +646,12 @@ def linear_int8(input: Tensor, weight_int8: Tensor, weight_scales: Tensor, bias:
     s = weight_scales.to(device=x.device, dtype=torch.float32).contiguous()
     b = None if bias is None else bias.to(device=x.device, dtype=dtype).contiguous()
     out = torch.empty(M, N, dtype=dtype, device=x.device)
-    ws_bytes = int((_native.lib().mbnb_linear_int8_workspace_bytes if DECODE_ONCE else _native.lib().mbnb_matmul_4bit_splitk_workspace_bytes)(M, N, K)) if M > 16 else 0   # split-K for mid-sized M
+    flags = 0 if DECODE_ONCE else MATMUL_FUSED_ONLY
+    ws_bytes = int(_native.lib().mbnb_linear_int8_workspace_bytes(M, N, K, flags)) if M > 16 else 0   # split-K partials / the dequantised weight
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes > 0 else None
     with torch.cuda.device(x.device):
-        check(_native.lib().mbnb_linear_int8_ex(ptr(x), dcode, M, K, ptr(w), ptr(s), N, ptr(b), ptr(out), ptr(ws), ws_bytes,
-                                                0 if DECODE_ONCE else MATMUL_FUSED_ONLY, stream_ptr(x.device)), "linear_int8")
+        check(_native.lib().mbnb_linear_int8(ptr(x), dcode, M, K, ptr(w), ptr(s), N, ptr(b), ptr(out), ptr(ws), ws_bytes,
+                                             flags, stream_ptr(x.device)), "linear_int8")
     return out.reshape(*input.shape[:-1], N)
 
 
@@ -804,11 +742,12 @@ def matmul_fp8_e4m3(input: Tensor, weight: Tensor, weight_scales: Tensor, bias: 
     s = weight_scales.to(device=x2.device, dtype=torch.float32).contiguous()
     b = None if bias is None else bias.to(device=x2.device, dtype=dtype).contiguous()
     out = torch.empty(M, N, dtype=dtype, device=x2.device)
-    ws_bytes = int((_native.lib().mbnb_linear_int8_workspace_bytes if DECODE_ONCE else _native.lib().mbnb_matmul_4bit_splitk_workspace_bytes)(M, N, K)) if M > 16 else 0
+    flags = 0 if DECODE_ONCE else MATMUL_FUSED_ONLY
+    ws_bytes = int(_native.lib().mbnb_linear_int8_workspace_bytes(M, N, K, flags)) if M > 16 else 0
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x2.device) if ws_bytes > 0 else None
     with torch.cuda.device(x2.device):
-        check(_native.lib().mbnb_linear_fp8_ex(ptr(x2), dcode, M, K, ptr(w), ptr(s), N, ptr(b), ptr(out), ptr(ws), ws_bytes,
-                                               0 if DECODE_ONCE else MATMUL_FUSED_ONLY, stream_ptr(x2.device)), "matmul_fp8_e4m3")
+        check(_native.lib().mbnb_linear_fp8(ptr(x2), dcode, M, K, ptr(w), ptr(s), N, ptr(b), ptr(out), ptr(ws), ws_bytes,
+                                            flags, stream_ptr(x2.device)), "matmul_fp8_e4m3")
     out = out.reshape(*lead, N)
     return out.squeeze(0) if is_1d else out
 
@@ -894,10 +833,10 @@ def outlier_linear(input: Tensor, weight_int8: Tensor, weight_scales: Tensor, ou
     ow = outlier_weights.to(device=dev, dtype=dtype).contiguous() if n_out else None
     b = None if bias is None else bias.to(device=dev, dtype=dtype).contiguous()
     out = torch.empty(M, N, dtype=dtype, device=dev)
-    ws_bytes = int(_native.lib().mbnb_outlier_linear_workspace_bytes_n(M, K, n_out))
+    ws_bytes = int(_native.lib().mbnb_outlier_linear_workspace_bytes(M, K, n_out))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
-        check(_native.lib().mbnb_outlier_linear_ws(ptr(x), dcode, M, K, ptr(w), ptr(s), N, ptr(oi), n_out, ptr(ow), ptr(b),
+        check(_native.lib().mbnb_outlier_linear(ptr(x), dcode, M, K, ptr(w), ptr(s), N, ptr(oi), n_out, ptr(ow), ptr(b),
                                                    ptr(out), ptr(ws), ws_bytes, stream_ptr(dev)), "outlier_linear")
     return out.reshape(*input.shape[:-1], N)
 

@@ -168,7 +168,7 @@ def test_matmul_skinny_path(case):
     dict(M=40, N=11008, K=4096, dt=torch.bfloat16, cs=True, bs=32),
 ])
 def test_matmul_splitk_path(case, monkeypatch):
-    """128 x 128 tiles with K split over a caller workspace (mbnb_matmul_4bit_ws) and a deterministic slice reduction:
+    """128 x 128 tiles with K split over a caller workspace (mbnb_matmul_4bit) and a deterministic slice reduction:
     M > 192 (384 for N >= 8192), or blocksize != 64 (the mid-sized-batch kernel takes the rest)."""
     monkeypatch.setattr(bnb.functional, "DECODE_ONCE", False)   # the fused split-K kernels (callers without the N x K scratch)
     c = dict(case)
@@ -240,8 +240,9 @@ def test_matmul_mfma256_path(case, monkeypatch):
     """The fused 256x256 one-workgroup-per-CU kernel (dispatched for >= 96 tiles when the caller gives no N x K scratch)."""
     monkeypatch.setattr(bnb.functional, "DECODE_ONCE", False)
     c = dict(case)
+    four = c.get("bs", 64) == 64 and c["K"] % 256 == 0     # blocksize 64, whole absmax-by-4 groups: k_gemm_fused4 (round 4), else k_gemm256p
     kern = _oracle_vs_gpu_matmul(c.pop("M"), c.pop("N"), c.pop("K"), c.pop("dt"), seed=25, **c)
-    assert kern == "mfma256"
+    assert kern == ("mfma256f" if four else "mfma256")
 
 
 @pytest.mark.parametrize("case", [
@@ -276,7 +277,7 @@ def test_matmul_decode_once_path(case, monkeypatch):
     monkeypatch.setattr(bnb.functional, "DECODE_ONCE", False)
     y_fused = bnb.matmul_4bit(X, packed, st, b, c.get("cd"))
     assert "dense" not in _native.last_kernel()
-    if kern == "dequant+dense" and _native.last_kernel() == "mfma256":
+    if kern == "dequant+dense" and _native.last_kernel().startswith("mfma256"):
         assert torch.equal(y, y_fused), "dense and fused 256 x 256 kernels disagree"
     else:
         assert rel_fro(y, y_fused.cpu()) <= TOL[dt]
@@ -824,7 +825,7 @@ def test_linear_int8_skinny_path(M, N, K, dt, bias):
                                                  (200, 520, 448, torch.float16, True, "w8a16_mfma128")])
 def test_linear_int8_splitk_path(M, N, K, dt, bias, kern):
     """Linear8bit.forward for mid-sized M: 32 < M <= 256 with K % 256 == 0 -> k_gemm_small8 (weight operand decoded registers to
-    registers, gemm_small8.h); otherwise 128 x 128 tiles; K split over a workspace (mbnb_linear_int8_ws)."""
+    registers, gemm_small8.h); otherwise 128 x 128 tiles; K split over a workspace (mbnb_linear_int8)."""
     W = synthetic.normal((N, K), dt, seed=71, std=0.05)
     q, s = oracle.quantize_rowwise(W)
     x = synthetic.normal((M, K), dt, seed=72)
@@ -902,9 +903,8 @@ def test_linear_int8_randomized_dispatch_sweep():
 
 # --------------------------------------------------------------------------- round-2 additions: benched instantiation, config[4]
 def test_matmul_benched_instantiation_bf16_plain_full_size():
-    """The exact instantiation bench.py times (BASELINE metric): k_gemm256p<bf16, plain f32 absmax, absmax-by-4, byte
-    table> at M = N = K = 4096 -- 64 k-steps, i.e. 16 rotations of the absmax-by-4 slots and 32 of the stage parity
-    (the K = 256 cases above see a single rotation).  Row-sample parity vs the oracle: one row in every 256-row tile at a
+    """The exact instantiation bench.py times (BASELINE metric): dequantize_4bit into the scratch + k_gemm_dense<bf16> at
+    M = N = K = 4096, plain f32 absmax -- 64 k-steps, 32 rotations of the stage parity (the K = 256 cases above see two).  Row-sample parity vs the oracle: one row in every 256-row tile at a
     different in-tile position, the first rows, the last rows, and random ones; every column of those rows."""
     N = K = M = 4096
     W = synthetic.normal((N, K), torch.bfloat16, seed=1234)
@@ -919,10 +919,10 @@ def test_matmul_benched_instantiation_bf16_plain_full_size():
     bnb.functional.DECODE_ONCE = False
     try:
         Yf = bnb.matmul_4bit(X, packed, st)
-        assert _native.last_kernel() == "mfma256"
+        assert _native.last_kernel() == "mfma256f"
     finally:
         bnb.functional.DECODE_ONCE = True
-    assert torch.equal(Y, Yf), "k_gemm_dense and k_gemm256s disagree at 4096^3"
+    assert torch.equal(Y, Yf), "k_gemm_dense and k_gemm_fused4 disagree at 4096^3"
     rows = sorted(set([t * 256 + (37 * t + 5) % 256 for t in range(16)] + list(range(8)) + [M - 1, M - 2, M - 33] +
                       [int(v) for v in synthetic.uniform_u64(24, 19) % np.uint64(M)]))
     rows_t = torch.tensor(rows)
@@ -1231,9 +1231,10 @@ def test_synthetic_inputs_generated_on_the_gpu_equal_the_host_form():
                                                        (2500, 2600, 512, torch.float16, "fp4", False, True),
                                                        (2304, 3000, 768, torch.bfloat16, "nf4", True, True),
                                                        (4096, 4096, 1024, torch.float16, "nf4", True, False)])
-def test_matmul_fused4_flag_equals_the_decode_once_path(M, N, K, dt, qt, dq, with_bias):
-    """k_gemm_fused4 (round 3; csrc/gemm_fused4.h: the 4-bit decode inside the four-wave MFMA pipeline, one launch, no scratch),
-    reached through MBNB_MATMUL_FUSED4 of mbnb_matmul_4bit_ex: same B-operand bits and MFMA order as dequantize_4bit +
+def test_matmul_fused4_equals_the_decode_once_path(M, N, K, dt, qt, dq, with_bias):
+    """k_gemm_fused4 (csrc/gemm_fused4.h: the 4-bit decode inside the four-wave MFMA pipeline, one launch, no scratch) -- since round 4
+    what mbnb_matmul_4bit runs at blocksize 64 for a caller without the N x K scratch (workspace NULL, or MBNB_MATMUL_FUSED_ONLY with
+    one): same B-operand bits and MFMA order as dequantize_4bit +
     k_gemm_dense, hence the same output bits; plain and double-quantised absmax, both tables, ragged M / N, bias; and the oracle."""
     import ctypes
     lib = _native.lib()
@@ -1247,36 +1248,19 @@ def test_matmul_fused4_flag_equals_the_decode_once_path(M, N, K, dt, qt, dq, wit
     desc = bnb.functional._absmax_desc(st.absmax, st.state2, keep)
     out = torch.full((M, N), float("nan"), dtype=dt, device=DEV)
     code = _native.DTYPE_CODE[dt]
-    rc = lib.mbnb_matmul_4bit_ex(x.data_ptr(), M, K, packed.data_ptr(), ctypes.byref(desc), N, K, 64, _native.QUANT_CODE[qt], code,
-                                 None if bias is None else bias.data_ptr(), code, out.data_ptr(), None, 0, 2, _native.stream_ptr(DEV))
-    assert rc == 0, lib.mbnb_last_error()
-    assert _native.last_kernel() == "fused4"
-    assert torch.equal(out, y_ref)
+    ws = torch.empty(int(lib.mbnb_matmul_4bit_workspace_bytes(M, N, K, K, code, 0)), dtype=torch.uint8, device=DEV)
+    assert ws.numel() >= N * K * 2
+    for wsp, wsb, flags in ((None, 0, 0), (ws.data_ptr(), ws.numel(), 1)):    # no workspace; a workspace the caller does not want the weight in
+        out.fill_(float("nan"))
+        rc = lib.mbnb_matmul_4bit(x.data_ptr(), M, K, packed.data_ptr(), ctypes.byref(desc), N, K, 64, _native.QUANT_CODE[qt], code,
+                                  None if bias is None else bias.data_ptr(), code, out.data_ptr(), wsp, wsb, flags, _native.stream_ptr(DEV))
+        assert rc == 0, lib.mbnb_last_error()
+        assert _native.last_kernel() == "mfma256f"
+        assert torch.equal(out, y_ref)
     rows = torch.arange(0, M, max(1, M // 32))[:32]
     op, oa, os2 = oracle.quantize_4bit(W, 64, qt, dq)
     ref = oracle.matmul_4bit(x.cpu()[rows], op, oa, (N, K), 64, qt, dt, None if bias is None else bias.cpu(), None, os2)
     assert rel_fro(out.cpu()[rows], ref) <= TOL[dt]
-
-
-@pytest.mark.parametrize("M,N,K,dt,qt,with_bias", [(4096, 4096, 4096, torch.bfloat16, "nf4", False), (4000, 2560, 2048, torch.float16, "fp4", True),
-                                                   (3900, 1000, 2048, torch.bfloat16, "nf4", True)])
-def test_matmul_in_launch_decode_equals_the_two_launch_path(M, N, K, dt, qt, with_bias, monkeypatch):
-    """k_gemm_dq (round 3, csrc/gemm_dq.h; functional.DECODE_IN_LAUNCH, off by default): the weight decoded once INSIDE the GEMM
-    launch by the launch's own workgroups, handed between them through agent-scope flags.  Same Wd bits and the same pipeline as
-    dequantize_4bit + k_gemm_dense -> the same output bits; repeated calls (the flags must come back to zero each time); no
-    hand-off may time out."""
-    W = synthetic.normal((N, K), dt, seed=411)
-    x = synthetic.normal((M, K), dt, seed=412).to(DEV)
-    bias = synthetic.normal((N,), dt, seed=413).to(DEV) if with_bias else None
-    packed, st = bnb.quantize_4bit(W.to(DEV), blocksize=64, quant_type=qt)
-    y_ref = bnb.matmul_4bit(x, packed, st, bias)
-    assert _native.last_kernel().startswith("dequant+dense")
-    monkeypatch.setattr(bnb.functional, "DECODE_IN_LAUNCH", True)
-    for _ in range(3):
-        y = bnb.matmul_4bit(x, packed, st, bias)
-        assert _native.last_kernel() == "dq_inlaunch"
-        assert torch.equal(y, y_ref)
-    assert bnb.functional.in_launch_errors() == 0
 
 
 @pytest.mark.parametrize("N,K,dt,qt,dq,with_bias", [(4096, 4096, torch.bfloat16, "nf4", False, False), (4096, 4096, torch.float16, "nf4", True, True),
@@ -1307,32 +1291,6 @@ def test_matmul_m1_lean_gemv_vs_oracle(N, K, dt, qt, dq, with_bias):
     assert rel_fro(y2[:1].cpu(), y.cpu()) <= TOL[dt]
 
 
-@pytest.mark.parametrize("M,N,K,dt,qt,dq,with_bias", [(4096, 4096, 4096, torch.bfloat16, "nf4", False, False), (4000, 2560, 2048, torch.float16, "fp4", False, True),
-                                                      (3900, 2500, 2048, torch.bfloat16, "nf4", True, True), (4096, 11008, 1024, torch.bfloat16, "nf4", True, False)])
-@pytest.mark.parametrize("mode", ["one_stream", "two_streams", "split"])
-def test_matmul_decode_beside_equals_the_two_launch_path(M, N, K, dt, qt, dq, with_bias, mode, monkeypatch):
-    """csrc/gemm_beside.h (round 3; functional.DECODE_BESIDE, off by default): the dequantise pass as a 28-register kernel whose waves
-    fit BESIDE k_gemm_dense's on a SIMD, handing slabs of 512 k to the gated GEMM through agent-scope flags -- in the three launch
-    arrangements the library has (one stream; two streams with fork / join; first slab in the caller's stream, the rest beside).  Same
-    Wd bits and pipeline as dequantize_4bit + k_gemm_dense -> same output bits; a different weight through the same scratch on the
-    second call (no stale line of the previous one); ragged M and N (a partial tile column has fewer decoders); flags back to zero."""
-    monkeypatch.setattr(bnb.functional, "BESIDE_SIDE_STREAM", mode == "two_streams")
-    monkeypatch.setattr(bnb.functional, "BESIDE_SPLIT", mode == "split")
-    x = synthetic.normal((M, K), dt, seed=432).to(DEV)
-    bias = synthetic.normal((N,), dt, seed=433).to(DEV) if with_bias else None
-    for rep in range(3):
-        W = synthetic.normal((N, K), dt, seed=431 + 10 * rep, std=0.05 if dq else 1.0)
-        packed, st = bnb.quantize_4bit(W.to(DEV), blocksize=64, quant_type=qt, compress_statistics=dq)
-        monkeypatch.setattr(bnb.functional, "DECODE_BESIDE", False)
-        y_ref = bnb.matmul_4bit(x, packed, st, bias)
-        assert _native.last_kernel().startswith("dequant+dense")
-        monkeypatch.setattr(bnb.functional, "DECODE_BESIDE", True)
-        y = bnb.matmul_4bit(x, packed, st, bias)
-        assert _native.last_kernel() == "decode_beside+gated"
-        assert torch.equal(y, y_ref)
-    assert bnb.functional.in_launch_errors() == 0
-
-
 @pytest.mark.parametrize("M,N,K,dt,qt,dq,with_bias,kern", [(512, 4096, 4096, torch.bfloat16, "nf4", False, False, "mfma_small"),
                                                            (450, 4096, 4096, torch.float16, "fp4", True, True, "mfma_small"),
                                                            (300, 1000, 3072, torch.bfloat16, "nf4", False, True, "mfma_small_splitk"),
@@ -1356,33 +1314,6 @@ def test_matmul_257_to_512_rows_stay_fused_where_one_round_serves_them(M, N, K, 
     rows = torch.tensor(sorted(set([0, 1, 127, 128, 255, 256, 257, M - 1] + [int(v) for v in synthetic.uniform_u64(24, 77) % np.uint64(M)])))
     ref = oracle.matmul_4bit(x[rows], op, oa, (N, K), 64, qt, dt, bias, None, os2)
     assert rel_fro(y.cpu()[rows], ref) <= TOL[dt]
-
-
-def test_matmul_decode_beside_inside_a_graph_capture(monkeypatch):
-    """The decode-beside path captured into a HIP graph (one-stream arrangement: the gated GEMM becomes an ordinary kernel node behind the
-    decoder's; two-stream arrangement: fork / join edges) replays to the bits of the eager two-launch result."""
-    M, N, K = 4096, 2560, 2048
-    W = synthetic.normal((N, K), torch.bfloat16, seed=451)
-    x = synthetic.normal((M, K), torch.bfloat16, seed=452).to(DEV)
-    packed, st = bnb.quantize_4bit(W.to(DEV), blocksize=64, quant_type="nf4")
-    y_ref = bnb.matmul_4bit(x, packed, st)
-    for side in (False, True):
-        monkeypatch.setattr(bnb.functional, "DECODE_BESIDE", True)
-        monkeypatch.setattr(bnb.functional, "BESIDE_SIDE_STREAM", side)
-        s = torch.cuda.Stream()
-        with torch.cuda.stream(s):
-            y_warm = bnb.matmul_4bit(x, packed, st)            # sync area of this stream allocated and cleared outside the capture
-            assert _native.last_kernel() == "decode_beside+gated"
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=s):
-                y = bnb.matmul_4bit(x, packed, st)
-        for _ in range(3):
-            g.replay()
-        torch.cuda.synchronize()
-        assert torch.equal(y, y_ref) and torch.equal(y_warm, y_ref)
-        monkeypatch.setattr(bnb.functional, "DECODE_BESIDE", False)
-    assert bnb.functional.in_launch_errors() == 0
 
 
 @pytest.mark.gpu

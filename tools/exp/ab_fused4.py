@@ -1,4 +1,4 @@
-"""A/B of the four-wave fused kernel (k_gemm_fused4, flag MBNB_MATMUL_FUSED4) against the decode-once path (dequantize_4bit +
+"""A/B of the four-wave fused kernel (k_gemm_fused4; the no-scratch kernel of mbnb_matmul_4bit since round 4) against the decode-once path (dequantize_4bit +
 k_gemm_dense) and the 8-wave fused k_gemm256s (FUSED_ONLY): bit equality of the outputs, then interleaved timing (HIP events
 around N launches, variants alternating inside one process).   python tools/exp/ab_fused4.py [check|time] [M N K] [dq]"""
 import ctypes
@@ -22,7 +22,7 @@ def call(x, packed, state, flags, bias=None, ws=None):
     desc = F._absmax_desc(state.absmax, state.state2, keep)
     out = torch.empty(M, N, dtype=x.dtype, device=dev)
     code = _native.DTYPE_CODE[x.dtype]
-    rc = lib.mbnb_matmul_4bit_ex(x.data_ptr(), M, K, packed.data_ptr(), ctypes.byref(desc), N, Kw, state.blocksize,
+    rc = lib.mbnb_matmul_4bit(x.data_ptr(), M, K, packed.data_ptr(), ctypes.byref(desc), N, Kw, state.blocksize,
                                  _native.QUANT_CODE[state.quant_type], code, None if bias is None else bias.data_ptr(), code,
                                  out.data_ptr(), None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel(), flags,
                                  _native.stream_ptr(dev))
@@ -52,10 +52,10 @@ def main():
     bias = torch.randn(N, generator=g, device=dev).to(dt)
     packed, st = bnb.quantize_nf4(W, blocksize=64, compress_statistics=dq)
     Kw = F._padded(K, 64)
-    ws = torch.empty(int(lib.mbnb_matmul_4bit_workspace_bytes_kw(M, N, K, Kw)), dtype=torch.uint8, device=dev)
+    ws = torch.empty(int(lib.mbnb_matmul_4bit_workspace_bytes(M, N, K, Kw, _native.DTYPE_CODE[dt], 0)), dtype=torch.uint8, device=dev)
     y_ref = call(x, packed, st, 0, None, ws)
     k_ref = _native.last_kernel()
-    y_f4 = call(x, packed, st, 2, None, None)
+    y_f4 = call(x, packed, st, 0, None, None)   # no workspace: the fused kernel (k_gemm_fused4 since round 4)
     k_f4 = _native.last_kernel()
     torch.cuda.synchronize()
     print("kernels:", k_ref, k_f4, flush=True)
@@ -73,7 +73,7 @@ def main():
     print("equal (bias):", torch.equal(yb_ref, yb_f4), flush=True)
     if mode != "time":
         return
-    variants = {"dequant+dense": lambda: call(x, packed, st, 0, None, ws), "fused4": lambda: call(x, packed, st, 2, None, None),
+    variants = {"dequant+dense": lambda: call(x, packed, st, 0, None, ws), "fused4": lambda: call(x, packed, st, 0, None, None),
                 "fused 8-wave": lambda: call(x, packed, st, 1, None, None)}
     for f in variants.values():
         for _ in range(50):

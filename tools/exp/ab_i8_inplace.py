@@ -16,7 +16,7 @@ def call(A, B, sa, sb, odt, ws):
     N = B.shape[1]
     out = torch.empty(M, N, dtype=odt, device=dev)
     rc = lib.mbnb_matmul_int8(A.data_ptr(), B.data_ptr(), sa.data_ptr(), sb.data_ptr(), M, N, K, _native.DTYPE_CODE[odt], out.data_ptr(),
-                              None if ws is None else ws.data_ptr(), _native.stream_ptr(dev))
+                              None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel(), _native.stream_ptr(dev))
     assert rc == 0, (rc, lib.mbnb_last_error())
     return out
 

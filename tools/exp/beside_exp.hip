@@ -4,7 +4,7 @@
 //   the sync area from byte 16384 (the sync buffer must be >= 1 MiB).
 #define GB_STAMPS 1
 #include <hip/hip_ext.h>
-#include "../../mps_bitsandbytes_amd/csrc/gemm_beside.h"
+#include "parked/gemm_beside.h"
 namespace mbnb {
 void set_error(const char *, ...) {}
 void set_kernel_name(const char *) {}

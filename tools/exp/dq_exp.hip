@@ -2,7 +2,7 @@
 // The scratch must already hold the dequantised weight (the ablated variants skip part of the producer work).
 #include <cstdarg>
 #include <cstdio>
-#include "../../mps_bitsandbytes_amd/csrc/gemm_dq.h"
+#include "parked/gemm_dq.h"
 namespace mbnb {
 void set_error(const char *, ...) {}
 void set_kernel_name(const char *) {}

@@ -13,7 +13,7 @@
 // instead of two k16 per MFMA); parity is against the oracle, as for every kernel.
 #pragma once
 
-#include "../../mps_bitsandbytes_amd/csrc/gemm256s.h"
+#include "parked/gemm256s.h"
 
 namespace mbnb {
 

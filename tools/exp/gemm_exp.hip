@@ -3,7 +3,7 @@
 // shipping kernel and times all of them interleaved in one process (cdna_hip_programming.md rule 24).
 #include <cstdarg>
 #include <cstdio>
-#include "../../mps_bitsandbytes_amd/csrc/gemm256s.h"
+#include "parked/gemm256s.h"
 #include "gemm256t.h"
 #include "gemm256d.h"
 #include "gemm256v.h"

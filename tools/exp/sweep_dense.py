@@ -48,12 +48,12 @@ for shp in args.shapes.split(";"):
     Wd = torch.empty(N, K, dtype=torch.bfloat16, device=dev)
     keep = []
     desc = F._absmax_desc(state.absmax, state.state2, keep)
-    ws_bytes = max(int(lib.mbnb_matmul_4bit_workspace_bytes(M, N, K)), 16 * M * N * 4) + 256
+    ws_bytes = max(int(lib.mbnb_matmul_4bit_workspace_bytes(M, N, K, K, BF16, 0)), 16 * M * N * 4) + 256
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     assert ws.data_ptr() % 256 == 0
 
     def fused():
-        rc = lib.mbnb_matmul_4bit_ex(X.data_ptr(), M, K, packed.data_ptr(), ctypes.byref(desc), N, K, 64, _native.QUANT_CODE["nf4"], BF16,
+        rc = lib.mbnb_matmul_4bit(X.data_ptr(), M, K, packed.data_ptr(), ctypes.byref(desc), N, K, 64, _native.QUANT_CODE["nf4"], BF16,
                                      None, BF16, out.data_ptr(), ws.data_ptr(), ws_bytes, 1, st)
         assert rc == 0, rc
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""OutlierAwareLinear forward (mbnb_outlier_linear_ws) at M = N = K = 4096, fp16, bias, by number of outlier columns: device
+"""OutlierAwareLinear forward (mbnb_outlier_linear) at M = N = K = 4096, fp16, bias, by number of outlier columns: device
 time per forward (HIP events, median of 5 x 50) and the int8 kernel that carried it.
     PYTHONPATH=. python tools/outlier_cols_sweep.py"""
 import numpy as np
