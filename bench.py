@@ -343,7 +343,16 @@ def spawn_ranks(args):
     env.setdefault("MASTER_ADDR", "127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
-    sys.exit(subprocess.call(cmd, env=env))
+    # stdout (rank 0's JSON line) passes straight through; stderr is relayed AND kept, so that a run that dies (a first 8-GPU run
+    # nobody could rehearse) leaves its reason in the one line the driver records
+    proc = subprocess.run(cmd, env=env, stderr=subprocess.PIPE, text=True, errors="replace")
+    if proc.stderr:
+        sys.stderr.write(proc.stderr)
+        sys.stderr.flush()
+    if proc.returncode != 0:
+        print(json.dumps({"error": f"the {args.gpus} child ranks exited with status {proc.returncode}", "n_gpus": args.gpus,
+                          "cmd": " ".join(cmd[1:8]) + " ...", "stderr_tail": (proc.stderr or "")[-1500:]}), flush=True)
+    sys.exit(proc.returncode)
 
 
 class Timer:
@@ -594,6 +603,10 @@ def measure(args, wl, ctx):
             traffic = json.load(open(prof))
         except Exception:
             traffic = {}
+    # `traffic` figures are PMC counters collected by tools/profile_round.sh (rocprofv3 --pmc cannot run inside this process);
+    # the file says which build and day they are from, and the line repeats it so that a stale file is visible
+    src_ = traffic.get("_source", {}) if isinstance(traffic.get("_source"), dict) else {}
+    traffic_source = f"profiles/traffic.json: commit {src_.get('commit', 'unrecorded')}, {src_.get('date', 'undated')}, {src_.get('tag', '')}".strip(", ")
     if wl == "nf4_m1":
         gbs = bytes_per_launch / (kern_ms * 1e-3) / 1e9
         out["metric"] = "effective GB/s, fused NF4 dequant+GEMV 4096x4096 M=1 (HBM, 64 rotating layers)"
@@ -602,7 +615,7 @@ def measure(args, wl, ctx):
         out["no_prewarm"]["value"] = round(bytes_per_launch * 64 * world / (cold[0] / args.steps) / 1e9, 2)
         out["roofline"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                            "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": traffic.get("k_gemv4_bytes_per_launch"),
-                           "kernel_us": round(kern_ms * 1e3, 3)}
+                           "kernel_us": round(kern_ms * 1e3, 3), "traffic_source": traffic_source}
     else:
         tflops = total_flops / (elapsed / args.steps) / 1e12
         peak = PEAK_TFLOPS[name]
@@ -626,7 +639,7 @@ def measure(args, wl, ctx):
         tkey = {"nf4_m4096": "nf4_m4096_step_bytes", "nf4dq_ffn": "nf4dq_ffn_step_bytes", "int8_4096": "int8_4096_step_bytes"}[wl]
         out["roofline"] = {"bound": "mfma", "scope": "the whole step (all launches of one matmul call)", "achieved": round(kern_tflops, 2),
                            "peak": peak, "unit": unit, "frac": round(kern_tflops / peak, 4), "traffic": traffic.get(tkey),
-                           "kernel_us": round(kern_ms * 1e3, 2),
+                           "kernel_us": round(kern_ms * 1e3, 2), "traffic_source": traffic_source,
                            "kernel_us_note": "HIP events around the K steps of the median repetition / K (includes the inter-launch boundaries)"}
         lib, sp = _native.lib(), _native.stream_ptr(dev)
         st_ = torch.cuda.current_stream()
@@ -667,12 +680,18 @@ def measure(args, wl, ctx):
                 "kernel": "k_gemm_dense", "kernel_us": round(dense_us, 2), "achieved": round(d_tflops, 2), "frac": round(d_tflops / peak, 4),
                 "traffic": traffic.get("k_gemm_dense_bytes_per_launch") if wl == "nf4_m4096" else traffic.get("nf4dq_ffn_gemm_dense_bytes_per_launch"),
                 "note": "k_gemm_dense ALONE on the already dequantised weight (HIP events around K launches / K): NOT the operation the metric names"}
+            # the same three numbers as scalars of `roofline` (records that keep only an object's scalar members keep these)
+            out["roofline"]["dom_kernel"] = "k_gemm_dense"
+            out["roofline"]["dom_kernel_us"] = round(dense_us, 2)
+            out["roofline"]["dom_frac"] = round(d_tflops / peak, 4)
             out["roofline"]["dequantize_us"] = round(deq_us, 2)
             out["roofline"]["dequantize_us_note"] = ("the public dequantize_4bit launch ALONE (eager call: includes its host side); inside the step the pass stores write-through "
                                                      "(four dwords per thread on weights of up to 32 Mi elements), see step_minus_dense_us")
             out["roofline"]["step_minus_dense_us"] = round(out["roofline"]["kernel_us"] - dense_us, 2)
             del Wd, Yd
         if wl == "int8_4096":
+            if kernel_name == "i8_inplace4":     # one launch: the operation IS its dominant kernel
+                out["roofline"]["dom_kernel"], out["roofline"]["dom_kernel_us"], out["roofline"]["dom_frac"] = "k_gemm_i8_inplace", out["roofline"]["kernel_us"], out["roofline"]["frac"]
             out["roofline"]["launches"] = (["k_gemm_i8_inplace (four waves, B [K, N] read in place: no transpose pass, no workspace)"] if kernel_name == "i8_inplace4"
                                            else ["k_transpose_i8 (B [K, N] -> [N, K] into the workspace)", "k_gemm_dense<I8>"] if "dense" in kernel_name else [kernel_name])
 
@@ -801,6 +820,26 @@ def measure(args, wl, ctx):
                     "bare_mfma_loop_bf16_tflops": None if mfma_tflops is None else round(mfma_tflops, 1),
                     "bare_mfma_note": "v_mfma_f32_32x32x16_bf16 back to back on every SIMD, nothing else: the sustained matrix rate at the clock the chip holds under MFMA load",
                     "dtod_copy_gbs_read_plus_write": round(2.0 * (1 << 30) / (copy_ms * 1e-3) / 1e9, 0)}
+                # The distance to the 0.60 target against MEASURED limits of this box: the bare matrix rate, and the
+                # fill rate of the two 33.5 MB writes the operation cannot avoid (the scratch by the dequantise pass, the output by the
+                # epilogue -- one tile per CU: every workgroup stores at the end, nothing left to overlap them with).
+                fillbuf = torch.empty(M * N, dtype=dt, device=dev)
+                fillbuf.zero_()
+                fill_us = min(event_time_ms(fillbuf.zero_, 50) for _ in range(3)) * 1e3
+                del fillbuf
+                if mfma_tflops:
+                    mfma_us = 2.0 * M * N * K / (mfma_tflops * 1e12) * 1e6
+                    floor_us = mfma_us + 2.0 * fill_us
+                    out["roofline"]["ceiling"] = {
+                        "bare_mfma_tflops": round(mfma_tflops, 1), "bare_mfma_frac_of_peak": round(mfma_tflops / peak, 4),
+                        "mfma_only_us": round(mfma_us, 2), "fill_33MB_us": round(fill_us, 2),
+                        "floor_us": round(floor_us, 2), "floor_frac": round(2.0 * M * N * K / (floor_us * 1e-6) / 1e12 / peak, 4),
+                        "kstep_cycles_per_2048_mfma_cycles": 2268, "clock_ghz_in_kernel": 1.76,
+                        "note": "floor = every MFMA of the product at this box's bare-loop rate + the scratch write + the output write at this box's fill rate "
+                                "(torch zero_ of 33.5 MB, back to back), nothing else; k-step cycles and in-kernel clock: s_memtime stamps, "
+                                "profiles/r03_dense_kstep_stamps.txt (the k-loop is 0.91 MFMA-busy and waits for nothing)"}
+                    out["roofline"]["ceiling_floor_us"] = round(floor_us, 2)
+                    out["roofline"]["ceiling_floor_frac"] = out["roofline"]["ceiling"]["floor_frac"]
             except Exception as e:  # context only: never fails the bench
                 out["roofline"]["empirical"] = {"error": str(e)[:200]}
     if rank == 0 and wl == "int8_4096" and not args.no_empirical:
@@ -830,6 +869,28 @@ def measure(args, wl, ctx):
             finally:
                 oracle.set_num_threads(nproc)
     return out
+
+
+def digest(out):
+    """All four GPU configs of BASELINE.json in <= 600 characters: [value, roofline frac of the operation, step us, dominant-kernel us]
+    per workload (nf4_m1: [GB/s, frac, us per layer]); batch_sweep_us: M -> us of matmul_4bit at 4096 x 4096."""
+    def row(o):
+        r = o.get("roofline") or {}
+        return [o.get("value"), r.get("frac"), r.get("kernel_us"), r.get("dom_kernel_us")]
+    d = {"nf4_m4096": row(out)}
+    for o in out.get("secondary", []):
+        key = o.get("workload_key")
+        if "error" in o:
+            d[key] = "error"
+        elif key == "nf4_m1":
+            d[key] = [o.get("value"), (o.get("roofline") or {}).get("frac"), (o.get("roofline") or {}).get("kernel_us")]
+        else:
+            d[key] = row(o)
+    if "gemv" in out:
+        d["gemv_bf16"] = [out["gemv"]["roofline"]["achieved"], out["gemv"]["roofline"]["frac"], out["gemv"]["us_per_layer"]]
+    if "batch_sweep" in out:
+        d["batch_sweep_us"] = {str(e["M"]): e["us"] for e in out["batch_sweep"]}
+    return d
 
 
 def main():
@@ -895,6 +956,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        out["digest"] = digest(out)      # LAST key: survives a record that keeps only the tail of the line
         print(json.dumps(out))
 
 

@@ -21,7 +21,8 @@ int dequantize_4bit_dispatch(const uint8_t *, const AbsmaxView &, int64_t, int64
 // From 96 tiles of 256 x 256 up never split, although two slices measure up to 13 % faster at 96-128 tiles: an unsplit product
 // has the same bits for a row whatever M it is computed in (the tile shape does not change a row's summation order, the
 // slice count does), which is what lets row shards and row chunks of a large batch (sharding.py, bench.py --gpus N
-// --verify) be compared bit for bit with the unsharded result.
+// --verify) be compared bit for bit with the unsharded result -- for shards and chunks of MORE THAN 512 ROWS: since round 3
+// matmul_4bit_dispatch offers 257-512 rows to k_gemm_small first (gemm_small_one_round), whose summation order is its own.
 // Round 3: a third tile shape, 128 x 128 on three LDS stages (fm = 2, gemm_dense128.h; never split): 0.47 us per k-step with every
 // CU busy, 0.36 us at <= 128 tiles (tools/exp/ab_dense128.py, profiles/r03_dense128_ab.txt).  It replaces the split plans wherever
 // its tiles fit the chip in one round: 1024 x 4096 x 4096 35.9 us against 45.9 (256 x 128 tiles x 2 slices + the reduction pass),

@@ -8,6 +8,12 @@ Forward: `functional.linear_int8` decodes the int8 rows inside the GEMM at small
 dequantize_rowwise -> dense GEMM; with `use_cache` (the default, as in the reference) the dequantised weight of that step is
 KEPT in `_weight_cache` (reference :70-85) and later large-batch calls run the dense GEMM alone -- same bits as the
 uncached call, minus the dequantise pass.  `use_cache=False` re-dequantises into transient scratch on every call.
+
+Cost and validity of the cache: it holds N x K x 2 bytes per layer after the layer's first large-batch forward (an int8 model's
+weight memory roughly triples once every layer has seen a prefill; `clear_cache()` or `use_cache=False` gives it back).  It is
+keyed on the buffers it was made from -- their storage pointers and in-place version counters -- so `load_state_dict`, `copy_`
+into `weight_int8` / `weight_scales`, `.to()` / `_apply` all invalidate it (the reference's cache has no such check: there a
+reloaded checkpoint keeps serving the old weights until `clear_cache()`).
 """
 from typing import Optional
 
@@ -30,6 +36,11 @@ class Linear8bit(QuantizedModule):
         self.register_buffer('weight_scales', torch.ones(out_features, dtype=torch.float32, device=device))
         self._init_bias(bias, device)
         self._weight_cache: Optional[Tensor] = None
+        self._weight_cache_key = None
+
+    def _cache_key(self):
+        w, s = self.weight_int8, self.weight_scales
+        return (w.data_ptr(), w._version, s.data_ptr(), s._version, w.device, self.compute_dtype)
 
     def forward(self, x: Tensor) -> Tensor:
         if self.use_cache and self.compute_dtype in (torch.float16, torch.bfloat16) and x.is_cuda:
@@ -42,16 +53,28 @@ class Linear8bit(QuantizedModule):
     # dequantized weight, kept while use_cache is set (reference :70-89): large-batch forwards, LoRA merges, debugging
     def _get_weight(self) -> Tensor:
         cached = self._weight_cache if self.use_cache else None
-        if cached is not None and (cached.device != self.weight_int8.device or cached.dtype != self.compute_dtype):
-            cached = None     # the module was moved / re-typed since the weight was cached
+        key = self._cache_key()
+        if cached is not None and self._weight_cache_key != key:
+            cached = None     # the buffers were reloaded, written in place, moved or re-typed since the weight was cached
         if cached is None:
             cached = F.dequantize_rowwise(self.weight_int8, self.weight_scales, dtype=self.compute_dtype)
             if self.use_cache:
-                self._weight_cache = cached
+                self._weight_cache, self._weight_cache_key = cached, key
+            else:
+                self._weight_cache = self._weight_cache_key = None
         return cached
 
     def clear_cache(self):
         self._weight_cache = None
+        self._weight_cache_key = None
+
+    def _apply(self, fn, *args, **kwargs):
+        self.clear_cache()       # .to() / .cuda() / .half(): the cached copy belongs to the old placement
+        return super()._apply(fn, *args, **kwargs)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self.clear_cache()       # a loaded checkpoint replaces the weights the cache was made from
+        return super()._load_from_state_dict(*args, **kwargs)
 
     @classmethod
     def from_linear(cls, linear: nn.Linear, device=None, use_cache: bool = True,

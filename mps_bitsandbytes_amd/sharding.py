@@ -77,18 +77,21 @@ class ChunkedGather:
     def step(self, local_rows: torch.Tensor) -> torch.Tensor:
         b = self.count & 1
         self.count += 1
-        for w in self.pending[b]:
-            w.wait()
-        self.pending[b] = []
+        self._drain(b)
         buf = self.buffers[b]
         for i in range(self.chunks):
-            y = self.forward(local_rows[i * self.rc:(i + 1) * self.rc])
-            self.pending[b].append(dist.all_gather_into_tensor(buf[i].view(self.world * self.rc, self.N), y.contiguous(),
-                                                               group=self.group, async_op=True))
+            y = self.forward(local_rows[i * self.rc:(i + 1) * self.rc]).contiguous()
+            work = dist.all_gather_into_tensor(buf[i].view(self.world * self.rc, self.N), y, group=self.group, async_op=True)
+            # the chunk's shard stays referenced until its gather has been waited for: the collective reads it on another
+            # stream, and dropping the last reference would hand its memory back to the allocator of THIS stream
+            self.pending[b].append((work, y))
         return buf.permute(1, 0, 2, 3)   # [rank][chunk][row][N]: global row order; valid after finish()
+
+    def _drain(self, b: int) -> None:
+        for work, _shard in self.pending[b]:
+            work.wait()
+        self.pending[b] = []
 
     def finish(self) -> None:
         for b in range(2):
-            for w in self.pending[b]:
-                w.wait()
-            self.pending[b] = []
+            self._drain(b)

@@ -23,8 +23,15 @@ def test_gpus_flag_spawns_child_ranks():
                        env=_env(), capture_output=True, text=True, timeout=600)
     errs = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
     assert p.returncode != 0
-    # (the launcher stops the other rank as soon as one has failed, so one or two records arrive)
-    assert 1 <= len(errs) <= 2 and all("no GPU visible" in e["error"] and e["world"] == 2 for e in errs), p.stdout + p.stderr[-1500:]
+    # (the launcher stops the other rank as soon as one has failed, so one or two rank records arrive) ...
+    ranks = [e for e in errs if "rank" in e]
+    assert 1 <= len(ranks) <= 2 and all("no GPU visible" in e["error"] and e["world"] == 2 for e in ranks), p.stdout + p.stderr[-1500:]
+    # ... followed by the parent's own record: exit status and the tail of the children's stderr (round 4: a multi-GPU run that dies
+    # must be diagnosable from the one line a driver keeps)
+    last = errs[-1]
+    assert "rank" not in last and last["n_gpus"] == 2 and "child ranks exited with status" in last["error"]
+    assert "exitcode" in last["stderr_tail"] and len(last["stderr_tail"]) <= 1500
+    assert last["stderr_tail"][-200:] in p.stderr          # relayed as well as recorded
 
 
 def test_world_size_mismatch_is_refused():

@@ -640,6 +640,36 @@ def test_linear8bit_use_cache_keeps_the_dequantised_weight(M, N, K, dt):
         assert cached._weight_cache is None and torch.equal(y1, y0)
 
 
+def test_linear8bit_cache_follows_the_weights():
+    """a cached dequantised weight must not outlive the buffers it was made from -- after load_state_dict, an in-place
+    copy_ into weight_int8 / weight_scales, or .to(), large-batch forwards (cache) and small-batch forwards (fused kernels) have
+    to see the SAME weights."""
+    M, N, K, dt = 512, 3072, 256, torch.float16
+    assert bnb.functional.dense_path_applies(M, N, K)
+
+    def make(seed):
+        lin = torch.nn.Linear(K, N, bias=True)
+        lin.weight.data.copy_(synthetic.normal((N, K), torch.float32, seed=seed, std=0.05))
+        lin.bias.data.copy_(synthetic.normal((N,), torch.float32, seed=seed + 1))
+        return bnb.Linear8bit.from_linear(lin.to(dt).to(DEV), use_cache=True)
+
+    a, b = make(301), make(401)
+    x = synthetic.normal((M, K), dt, seed=97).to(DEV)
+    ya, yb = a(x), b(x)
+    assert a._weight_cache is not None and not torch.equal(ya, yb)
+    a.load_state_dict(b.state_dict())                       # same storage, new contents
+    assert torch.equal(a(x), yb), "large-batch forward served the weights of before load_state_dict"
+    assert torch.equal(a(x[:8]), b(x[:8]))
+    a.weight_int8.copy_(make(301).weight_int8)              # in-place write: version counter
+    a.weight_scales.copy_(make(301).weight_scales)
+    a.bias.data.copy_(make(301).bias.data)
+    assert torch.equal(a(x), ya), "large-batch forward served the weights of before copy_"
+    wd = a._weight_cache
+    assert torch.equal(a(x), ya) and a._weight_cache is wd, "an untouched layer keeps its cache"
+    a = a.to(torch.device("cuda", 0))                       # _apply drops the cache even when nothing moves
+    assert a._weight_cache is None and torch.equal(a(x), ya)
+
+
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("M,N,K,ldw,slices,tile,odt", [(300, 520, 256, 256, 1, 0, None), (515, 1000, 640, 704, 2, 128, torch.float32),
                                                        (1024, 768, 2048, 2048, 4, 256, None), (129, 257, 128, 136, 1, 128, torch.float16)])

@@ -69,7 +69,7 @@ def main():
         rows = torch.unique(bad[:, 0])
         print("bad cols:", cols.numel(), cols[:16].tolist(), "bad rows:", rows.numel(), rows[:16].tolist())
     yb_ref = call(x, packed, st, 0, bias, ws)
-    yb_f4 = call(x, packed, st, 2, bias, None)
+    yb_f4 = call(x, packed, st, 0, bias, None)
     print("equal (bias):", torch.equal(yb_ref, yb_f4), flush=True)
     if mode != "time":
         return
