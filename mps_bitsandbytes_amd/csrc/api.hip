@@ -77,7 +77,7 @@ int64_t gemm_f32_workspace_bytes(int64_t, int64_t, int64_t, int64_t);
 int64_t gemm_dense_workspace_bytes(int64_t, int64_t, int64_t, int64_t);
 bool gemm_dense_shape(int64_t, int64_t, int64_t, int64_t);
 int64_t gemm_dense_slices(int64_t, int64_t, int64_t);
-int gemm_dense_direct(const void *, const void *, int, const void *, int, void *, int64_t, int64_t, int64_t, int64_t, float *, int64_t, int,
+int gemm_dense_direct(const void *, const void *, int, const void *, int, void *, int64_t, int64_t, int64_t, int64_t, float *, int64_t, int, int,
                       hipStream_t);
 int matmul_int8_dispatch(const int8_t *, const int8_t *, const float *, const float *, int64_t, int64_t, int64_t, int, void *, void *, hipStream_t);
 int64_t matmul_int8_workspace_bytes(int64_t, int64_t, int64_t);
@@ -283,10 +283,12 @@ int64_t mbnb_linear_int8_workspace_bytes(int64_t M, int64_t N, int64_t K, int fl
 
 int mbnb_gemm_dense(const void *A, const void *W, int dtype, const void *bias, int out_dtype, void *out, int64_t M, int64_t N,
                     int64_t K, int64_t ldw, void *workspace, int64_t workspace_bytes, int slices, void *stream) {
-    // slices: bits 0-7 the K slices; bits 8-15 the row extent of a tile, 0 (library's choice), 128 or 256, in units of 128 rows
-    const int tile_m = ((slices >> 8) & 0xFF) * 128;
+    // slices: bits 0-7 the K slices; bits 8-15 the diagnostic tile code (0 the library's choice; 1 256 x 128 tiles, 2 256 x 256 tiles in uniform columns,
+    // 3 128 x 128 tiles, 5 / 6 / 7 a forced column-balanced grid of 32 (code + 1) | 32 code wide columns, bits 16-31 how many of the wider)
+    const int tile_m = ((slices >> 8) & 0xFF) * 128, forced_cols_a = (slices >> 16) & 0xFFFF;
     slices &= 0xFF;
-    if (tile_m != 0 && tile_m != 128 && tile_m != 256 && tile_m != 384) return fail(MBNB_ERR_ARG, "gemm_dense: tile code must be 0, 1, 2 or 3");
+    if (tile_m != 0 && tile_m != 128 && tile_m != 256 && tile_m != 384 && !(tile_m >= 640 && tile_m <= 896 && slices <= 1))
+        return fail(MBNB_ERR_ARG, "gemm_dense: tile code must be 0, 1, 2, 3, or 5-7 with one slice");
     if (tile_m == 384 && (K < 192 || (slices & 0xFF) > 1)) return fail(MBNB_ERR_ARG, "gemm_dense: the 128 x 128 tile needs K >= 192 and takes no K slices");
     if ((dtype != MBNB_F16 && dtype != MBNB_BF16) || !dtype_ok(out_dtype)) return fail(MBNB_ERR_ARG, "gemm_dense: bad dtype");
     if (M <= 0 || N <= 0 || K < 128 || K % 64 || ldw < K || ldw % 8) return fail(MBNB_ERR_SHAPE, "gemm_dense: bad shape");
@@ -301,7 +303,7 @@ int mbnb_gemm_dense(const void *A, const void *W, int dtype, const void *bias, i
     if (slices < 1 || slices > 16 || (int64_t)slices * 64 > K) return fail(MBNB_ERR_ARG, "gemm_dense: bad slice count");
     if (slices > 1 && (!workspace || workspace_bytes < (int64_t)slices * M * N * 4 || (reinterpret_cast<uintptr_t>(workspace) & 15)))
         return fail(MBNB_ERR_ARG, "gemm_dense: split-K needs slices * M * N * 4 bytes of 16-byte aligned workspace");
-    return gemm_dense_direct(A, W, dtype, bias, out_dtype, out, M, N, K, ldw, static_cast<float *>(workspace), slices, tile_m,
+    return gemm_dense_direct(A, W, dtype, bias, out_dtype, out, M, N, K, ldw, static_cast<float *>(workspace), slices, tile_m, forced_cols_a,
                              static_cast<hipStream_t>(stream));
 }
 

@@ -57,16 +57,50 @@ constexpr int GD_LDS = 4 * P_IMG;   // A0 A1 B0 B1; the epilogue's store staging
 //           piece per slot and CU); B2 = R0 = 100; the next tile's slice-0 reads in slots 100 .. 115.
 //   FM = 4 (256 n x 128 m tile, for grids that would leave CUs idle with 256 x 256): 64 slots; reads in slots 0 .. 11;
 //           B1 = 16; piece i of wave w in slot 16 + 2 i + (w & 1) (two pieces per slot and CU); B2 = R0 = 42.
-template <int FM> struct GdPlan {
-    static constexpr int NS = 16 * FM, NR = 8 + FM, NP = 8 + FM;
-    static constexpr int RS1 = FM == 8 ? 2 : 1;                  // slot stride of the slice-1 reads
-    static constexpr int B1 = FM == 8 ? 36 : 16, D0 = B1;
+// Round 4: FN < 8 n-fragments per wave (tiles of 32 FN columns: 224 / 192 / 160 wide, FM = 8 only) for the column-balanced grids of
+// k_gemm_dense_nb below -- NS = 2 FN FM slots, NR = NP = FN + FM:
+//   FN = 7: reads every other slot 0 .. 28; B1 = 32; pieces 32 + 4 i + w (i < 15); B2 = R0 = 94 (reads 94 .. 108 of 112).
+//   FN = 6: reads 0 .. 13; B1 = 16; pieces 16 + 4 i + w (i < 14); B2 = R0 = 78 (reads 78 .. 91 of 96).
+//   FN = 5: reads 0 .. 12; B1 = 13; pieces 13 + 4 i + w (i < 13); B2 = R0 = 66 (reads 66 .. 78 of 80).
+template <int FM, int FN = 8> struct GdPlan {
+    static_assert(FN == 8 || (FM == 8 && FN >= 5 && FN <= 7), "narrow tiles exist for the 256-row tile only");
+    static constexpr int NS = 2 * FN * FM, NR = FN + FM, NP = FN + FM;
+    static constexpr int RS1 = (FM == 8 && FN >= 7) ? 2 : 1;      // slot stride of the slice-1 reads
+    static constexpr int B1 = FM != 8 ? 16 : (FN == 8 ? 36 : FN == 7 ? 32 : FN == 6 ? 16 : 13), D0 = B1;
     static constexpr int DS = FM == 8 ? 4 : 2;                    // slot stride of a wave's pieces; wave offset = w & (DS - 1)
-    static constexpr int B2 = FM == 8 ? 100 : 42, R0 = B2;
+    static constexpr int B2 = FM != 8 ? 42 : (FN == 8 ? 100 : FN == 7 ? 94 : FN == 6 ? 78 : 66), R0 = B2;
+    static_assert(R0 >= FN * FM, "the next tile's slice 0 replaces this tile's only after its MFMAs");
     static_assert((NR - 1) * RS1 < B1, "slice 1 is in registers before barrier 1");
     static_assert(D0 + NP * DS <= B2, "every piece is issued before the vmcnt of barrier 2");
     static_assert(R0 + NR <= NS, "the next tile's slice 0 is in registers before the k-step ends");
 };
+
+// ---- tile -> workgroup map (round 4).  Blocks b, b + 8, ... share an XCD's L2 (MI355X_MICROARCH.md: blocks are dealt round-robin over
+// the 8 XCDs), so the walk over the tile grid is cut into pseudo-patches of 32 consecutive tiles and XCD x takes pseudo-patches x, x + 8, ...:
+// what an XCD's 32 CUs run together is one compact patch, and -- the walk starts at the WIDE tile columns of a column-balanced grid -- every
+// XCD gets the same mix of wide and narrow tiles to within one patch.  The walk itself: patches of PM x PN tiles, ragged at the grid's
+// edges (round 3 walked the columns beyond the last full patch one by one: 3 of 43 at N = 11008, and the whole grid when tiles_m % PM != 0),
+// patch columns outermost, inside a patch the m index fastest.
+__device__ __forceinline__ int gd_xcd_major(int bid, int nwg) {
+    const int full = (nwg >> 8) << 8;             // whole groups of 8 pseudo-patches
+    if (bid < full) {
+        const int i = bid >> 3;
+        return (((i >> 5) << 3) + (bid & 7)) * 32 + (i & 31);
+    }
+    const int rest = nwg - full, r = bid - full, q = rest >> 3, rr = rest & 7, xcd = r & 7;     // the last, partial group: one contiguous run per XCD
+    return full + (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (r >> 3);
+}
+template <int PM, int PN> __device__ __forceinline__ void gd_patch_walk(int v, int tiles_m, int tiles_n, int &tm, int &tn) {
+    const int col_tiles = tiles_m * PN, pcs = tiles_n / PN, prs = tiles_m / PM;
+    int pc = v / col_tiles, w = PN;
+    if (pc >= pcs) { pc = pcs; w = tiles_n - pcs * PN; }
+    const int v1 = v - pc * col_tiles;            // inside the patch column: tiles_m x w tiles
+    int pr = v1 / (PM * w), h = PM;
+    if (pr >= prs) { pr = prs; h = tiles_m - prs * PM; }
+    const int v2 = v1 - pr * PM * w;              // inside the patch: h x w tiles, m fastest
+    tm = pr * PM + v2 % h;
+    tn = pc * PN + v2 / h;
+}
 
 // I8 = true: the same kernel as an int8 GEMM (matmul_int8, functional.py:788-793).  X = A int8 [M, 2K bytes], Wd = B^T int8
 // [N, 2 ldw bytes] -- a row of 2K int8 moves and lands exactly like a row of K 16-bit values, and a lane's 16 bytes of a k32
@@ -77,58 +111,29 @@ template <int FM> struct GdPlan {
 // and the row's compact outlier activations [m, <= 32] (zero padded), operands straight from global / L2.  OUTL = 1: f16 outputs,
 // 2: bf16 outputs (the rounding chain is compiled for one type: every instruction of this epilogue runs 256 times per lane).
 // NCH: chunks of 32 outlier columns (1 or 2; f32 accumulation runs through the chunks, one rounding, as the reference's single GEMM).
-template <typename T, bool SPLITK, int FM = 8, bool I8 = false, int OUTL = 0, int NCH = 1>
-__global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, const T *__restrict__ Wd, const T *__restrict__ bias,
-                                                       void *__restrict__ out_v, int out_dtype, float *__restrict__ partial,
-                                                       int64_t M, int64_t N, int64_t K, int64_t ldw, int64_t k_per_slice,
-                                                       const float *__restrict__ sA, const float *__restrict__ sB, OutlierEpilogue ep) {
+// FN: n-fragments per wave (tile = 32 FN columns x 32 FM rows); the tile's origin (m0, n0) and its K slice come from the kernel wrappers below.
+template <typename T, bool SPLITK, int FM, bool I8, int OUTL, int NCH, int FN>
+__device__ __forceinline__ void gemm_dense_body(const T *__restrict__ X, const T *__restrict__ Wd, const T *__restrict__ bias,
+                                                void *__restrict__ out_v, int out_dtype, float *__restrict__ partial,
+                                                int64_t M, int64_t N, int64_t K, int64_t ldw, int64_t k_per_slice,
+                                                const float *__restrict__ sA, const float *__restrict__ sB, const OutlierEpilogue &ep,
+                                                const int64_t m0, const int64_t n0, const int slice) {
     static_assert(!(I8 && SPLITK), "the int8 form is not split");
     static_assert(OUTL == 0 || I8, "the outlier epilogue belongs to the int8 form");
+    static_assert(OUTL == 0 || FN == 8, "the outlier epilogue is written for the 256-wide tile");
     using Frag = typename Mfma16<T>::frag;
-    using Plan = GdPlan<FM>;
-    constexpr int TM = 32 * FM;                 // rows of A per tile: two waves of 16 FM
-    constexpr int PM = FM == 8 ? 4 : 8, PN = 32 / PM;   // XCD patch of 32 tiles: the one with the smallest operand perimeter
+    using Plan = GdPlan<FM, FN>;
+    constexpr int TM = 32 * FM, TN = 32 * FN;   // rows of A / rows of Wd per tile: two waves of 16 FM / 16 FN
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave >> 1, wm = wave & 1;
-
-    // ---- tile -> workgroup map (as k_gemm256s): blocks b, b+8, ... share an XCD's L2 -> compact PM (m) x PN (n) patches
-    const int64_t tiles_m = (M + TM - 1) / TM, tiles_n = (N + 255) >> 8;
-    const int64_t nwg = tiles_m * tiles_n;
-    int64_t bid = blockIdx.x;
-    int slice = 0;
-    if constexpr (SPLITK) {
-        slice = (int)(bid / nwg);
-        bid -= (int64_t)slice * nwg;
-    }
-    {
-        const int64_t q = nwg / 8, r = nwg % 8, xcd = bid % 8;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
-    }
-    // Round 3: tile columns that do not fill a patch (N = 11008: 43 columns) no longer switch the whole grid to the column-major
-    // order -- there every XCD walks all of A once per round of workgroups (PMC: 1.04 GB of fabric traffic per launch at
-    // 4096 x 11008 x 4096 against 0.21 GB algorithmic, profiles/traffic.json r03); the leading floor(tiles_n / PN) * PN columns keep
-    // their PM x PN patches, only the remainder is walked column by column.
-    int64_t tm, tn;
-    const int64_t full_n = (tiles_m % PM == 0) ? (tiles_n / PN) * PN : 0;
-    if (bid < tiles_m * full_n) {
-        const int64_t patch = bid >> 5, within = bid & 31;
-        const int64_t patches_m = tiles_m / PM;
-        tm = (patch % patches_m) * PM + (within % PM);
-        tn = (patch / patches_m) * PN + (within / PM);
-    } else {
-        const int64_t r = bid - tiles_m * full_n;
-        tm = r % tiles_m;
-        tn = full_n + r / tiles_m;
-    }
-    const int64_t m0 = tm * TM, n0 = tn << 8;
     const int64_t k_begin = SPLITK ? (int64_t)slice * k_per_slice : 0;
     const int64_t k_len = SPLITK ? (K - k_begin < k_per_slice ? K - k_begin : k_per_slice) : K;
     const int nk = (int)(k_len >> 6);
 
-    // ---- LDS-DMA: wave w moves A pieces FM w .. FM w + FM-1 and B pieces 8w..8w+7 (8 rows x 128 B each).  Piece p, lane l: row
+    // ---- LDS-DMA: wave w moves A pieces FM w .. FM w + FM-1 and B pieces FN w .. FN w + FN-1 (8 rows x 128 B each).  Piece p, lane l: row
     // 8p + (l >> 3), source chunk (l & 7) ^ ((row >> 1) & 7).  The ROW goes into the per-lane offset (8 + 8 VGPRs that never
     // change), the k position into the scalar offset: the descriptor's range check covers the per-lane offset only
     // (the scalar offset is excluded from it), and num_records = rows x pitch makes every row past M / N read as zeros
@@ -137,14 +142,14 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, 
     i32x4_t rs_a, rs_b;
     {
         const uint64_t pa = reinterpret_cast<uint64_t>(X + m0 * K + k_begin), pb = reinterpret_cast<uint64_t>(Wd + n0 * ldw + k_begin);
-        const int64_t rows_a = M - m0 < TM ? M - m0 : TM, rows_b = N - n0 < 256 ? N - n0 : 256;
+        const int64_t rows_a = M - m0 < TM ? M - m0 : TM, rows_b = N - n0 < TN ? N - n0 : TN;
         rs_a = i32x4_t{(int)(uint32_t)pa, (int)(uint32_t)(pa >> 32), (int)(rows_a * K * 2), 0x00020000};
         rs_b = i32x4_t{(int)(uint32_t)pb, (int)(uint32_t)(pb >> 32), (int)(rows_b * ldw * 2), 0x00020000};
     }
-    int voff_a[FM], voff_b[8];
+    int voff_a[FM], voff_b[FN];
 #pragma unroll
-    for (int pl = 0; pl < 8; pl++) {
-        const int row = 8 * (8 * wave + pl) + (lane >> 3);
+    for (int pl = 0; pl < FN; pl++) {
+        const int row = 8 * (FN * wave + pl) + (lane >> 3);
         voff_b[pl] = (int)(row * ldw * 2) + 16 * ((lane & 7) ^ ((row >> 1) & 7));
     }
 #pragma unroll
@@ -156,7 +161,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, 
     // Pieces 4 g .. 4 g + 3 of an operand share ONE M0 value: the instruction's 12-bit offset is added to the LDS address and to the
     // global address alike, so piece 4 g + m is issued with offset 1024 m from a per-lane offset that is 1024 m smaller.
 #pragma unroll
-    for (int pl = 0; pl < 8; pl++) voff_b[pl] -= (pl & 3) * 1024;
+    for (int pl = 0; pl < FN; pl++) voff_b[pl] -= (pl & 3) * 1024;
 #pragma unroll
     for (int pl = 0; pl < FM; pl++) voff_a[pl] -= (pl & 3) * 1024;
 #endif
@@ -173,10 +178,10 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, 
             c.rb[e] = __builtin_amdgcn_readfirstlane(rs_b[e]);
         }
         c.lwa = (uint32_t)__builtin_amdgcn_readfirstlane((int)(smem_base + (uint32_t)(P_A + wave * FM * 1024)));
-        c.lwb = (uint32_t)__builtin_amdgcn_readfirstlane((int)(smem_base + (uint32_t)(P_B + wave * 8192)));
+        c.lwb = (uint32_t)__builtin_amdgcn_readfirstlane((int)(smem_base + (uint32_t)(P_B + wave * FN * 1024)));
         return c;
     };
-    // piece q of the wave's NP (0 .. FM-1: A, FM .. FM+7: B) of the tile at byte position kb of the slice into stage `stage`
+    // piece q of the wave's NP (0 .. FM-1: A, FM .. FM+FN-1: B) of the tile at byte position kb of the slice into stage `stage`
     auto issue_piece = [&](auto qq, int stage, int kb, const DmaCtx &c) {
         constexpr int q = decltype(qq)::value, pl = q < FM ? q : q - FM;
         const uint32_t dst = (q < FM ? c.lwa : c.lwb) + (uint32_t)(stage * P_IMG + pl * 1024);
@@ -200,18 +205,18 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, 
 #pragma unroll
     for (int ks = 0; ks < 2; ks++) {
         const int f = r16 * ROW_BYTES + (((4 * ks + fq) ^ (r16 >> 1)) << 4);
-        fw[ks] = P_B + wn * 128 * ROW_BYTES + f;
+        fw[ks] = P_B + wn * 16 * FN * ROW_BYTES + f;
         fx[ks] = P_A + wm * 16 * FM * ROW_BYTES + f;
     }
-    Frag wf[2][8], xf[2][FM];     // [k32 slice][16-row fragment]
-    // read n of a slice, in the order the MFMAs want them: w0, x0 .. x(FM-1), w1 .. w7
+    Frag wf[2][FN], xf[2][FM];     // [k32 slice][16-row fragment]
+    // read n of a slice, in the order the MFMAs want them: w0, x0 .. x(FM-1), w1 .. w(FN-1)
     auto read_one = [&](int stage, auto kk, auto nn) {
         constexpr int ks = decltype(kk)::value, n = decltype(nn)::value;
         if constexpr (n == 0) wf[ks][0] = *reinterpret_cast<const Frag *>(smem + fw[ks] + stage * P_IMG);
         else if constexpr (n <= FM) xf[ks][n - 1] = *reinterpret_cast<const Frag *>(smem + fx[ks] + stage * P_IMG + (n - 1) * 16 * ROW_BYTES);
         else wf[ks][n - FM] = *reinterpret_cast<const Frag *>(smem + fw[ks] + stage * P_IMG + (n - FM) * 16 * ROW_BYTES);
     };
-    f32x4 acc[8][FM];   // never zero-filled: the first k-step's slice-0 MFMAs take a literal-zero C operand
+    f32x4 acc[FN][FM];   // never zero-filled: the first k-step's slice-0 MFMAs take a literal-zero C operand
 
     auto kbytes = [&](int t) { return (t < nk ? t : nk - 1) << 7; };   // past the end: the last tile again (never used)
 
@@ -236,7 +241,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, 
         constexpr bool FIRST = decltype(first)::value;
         const int kb2 = __builtin_amdgcn_readfirstlane(kbytes(j + 2));
         gd_static_for<Plan::NS>([&](auto tt) {
-            constexpr int t = decltype(tt)::value, ks = t / (8 * FM), f = (t % (8 * FM)) / FM, g = t % FM;
+            constexpr int t = decltype(tt)::value, ks = t / (FN * FM), f = (t % (FN * FM)) / FM, g = t % FM;
             if constexpr (t == Plan::B1) {
 #if GD_STAMPS == 3
                 { uint64_t a_, b_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(a_), "=s"(b_) :: "memory"); gd_sum += b_ - a_; gd_cnt++; }
@@ -315,18 +320,18 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, 
     }
 #endif
 
-    // ---- epilogue: acc[f][g][r] = out[m0 + 16 FM wm + 16 g + (lane & 15)][n0 + 128 wn + 16 f + 4 (lane >> 4) + r]
+    // ---- epilogue: acc[f][g][r] = out[m0 + 16 FM wm + 16 g + (lane & 15)][n0 + 16 FN wn + 16 f + 4 (lane >> 4) + r]
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     int tid2 = threadIdx.x;
     asm volatile("" : "+v"(tid2));      // nothing of the epilogue's address arithmetic is hoisted above the loop
     const int lane_e = tid2 & 63, er16 = lane_e & 15, efq = lane_e >> 4;
-    const int64_t n_base = n0 + wn * 128;
+    const int64_t n_base = n0 + wn * 16 * FN;
     if constexpr (SPLITK) {
         float *o = partial + (int64_t)slice * M * N;
 #pragma unroll
-        for (int f = 0; f < 8; f++)
+        for (int f = 0; f < FN; f++)
 #pragma unroll
             for (int g = 0; g < FM; g++) {
                 const int64_t m = m0 + wm * 16 * FM + 16 * g + er16, nn = n_base + 16 * f + 4 * efq;
@@ -341,7 +346,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, 
     if (out_dtype == MBNB_F32) {
         float *o = static_cast<float *>(out_v);
 #pragma unroll
-        for (int f = 0; f < 8; f++)
+        for (int f = 0; f < FN; f++)
 #pragma unroll
             for (int g = 0; g < FM; g++) {
                 const int64_t m = m0 + wm * 16 * FM + 16 * g + er16, nn = n_base + 16 * f + 4 * efq;
@@ -377,13 +382,13 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, 
     // the accumulator reads below are ordered asm): per 16-column group f the outlier weights of row n = 16 f + er16 (8 per
     // lane at outlier index 8 efq) and the four bias values of the lane's columns; per 16-row group the compact activations
     u32x4 wfr_all[OUTL ? 8 * NCH : 1];      // [chunk][f]
-    u32x2 bias_all[(OUTL || !I8) ? 8 : 1];   // 16-bit forms: the kernel's own bias (in T) travels the same way
+    u32x2 bias_all[(OUTL || !I8) ? FN : 1];   // 16-bit forms: the kernel's own bias (in T) travels the same way
     u32x4 xfr_all[OUTL ? FM * NCH : 1];     // [chunk][g]
     if constexpr (!I8) {
         if (bias != nullptr) {
             const uint16_t *bp = reinterpret_cast<const uint16_t *>(bias);
 #pragma unroll
-            for (int f = 0; f < 8; f++) {
+            for (int f = 0; f < FN; f++) {
                 const int64_t n = n_base + 16 * f + 4 * efq;
                 if (n + 4 <= N && (reinterpret_cast<uintptr_t>(bp + n) & 7) == 0) bias_all[f] = *reinterpret_cast<const u32x2 *>(bp + n);
                 else {
@@ -445,11 +450,11 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, 
     }
     // I8: the lane's 8 x 4 column scales sB / 127, requested once for both halves (in the fragment loop they cost a memory
     // latency and four IEEE divisions per column group and half)
-    float bv_all[I8 ? 8 : 1][4];
+    float bv_all[I8 ? FN : 1][4];
     if constexpr (I8) {
         const bool sb_vec = (reinterpret_cast<uintptr_t>(sB) & 15) == 0;
 #pragma unroll
-        for (int f = 0; f < 8; f++) {
+        for (int f = 0; f < FN; f++) {
             const int64_t n = n_base + 16 * f + 4 * efq;
             f32x4 t;
             if (sb_vec && n + 4 <= N) t = *reinterpret_cast<const f32x4 *>(sB + n);
@@ -478,7 +483,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, 
             }
         }
 #pragma unroll
-        for (int f = 0; f < 8; f++) {
+        for (int f = 0; f < FN; f++) {
             const int nl = 16 * f + 4 * efq;
             float bb[4] = {0.0f, 0.0f, 0.0f, 0.0f};
             if constexpr (WB && I8) {
@@ -545,7 +550,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, 
             piece[p] = u32x4{lo[0], lo[1], hi[0], hi[1]};
         }
         const int64_t n = n_base + ch * 8;
-        if (n < N) {
+        if (n < N && ch < 2 * FN) {     // (chunks past the wave's 16 FN columns belong to the neighbouring wave or tile)
             if (vec_ok && n + 8 <= N) {
 #pragma unroll
                 for (int p = 0; p < 4 * GP; p++) {
@@ -584,6 +589,48 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, 
     } else {
         epilogue16(No{}, No{});
     }
+}
+
+// The kernel of uniform 256-column tiles (every form: 16-bit, split-K, 256 x 128 tiles, int8, int8 + outliers).
+template <typename T, bool SPLITK, int FM = 8, bool I8 = false, int OUTL = 0, int NCH = 1>
+__global__ __launch_bounds__(256, 1) void k_gemm_dense(const T *__restrict__ X, const T *__restrict__ Wd, const T *__restrict__ bias,
+                                                       void *__restrict__ out_v, int out_dtype, float *__restrict__ partial,
+                                                       int64_t M, int64_t N, int64_t K, int64_t ldw, int64_t k_per_slice,
+                                                       const float *__restrict__ sA, const float *__restrict__ sB, OutlierEpilogue ep) {
+    constexpr int TM = 32 * FM;
+    constexpr int PM = FM == 8 ? 4 : 8, PN = 32 / PM;   // XCD patch of 32 tiles: the one with the smallest operand perimeter
+    const int tiles_m = (int)((M + TM - 1) / TM), tiles_n = (int)((N + 255) >> 8);
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x, slice = 0;
+    if constexpr (SPLITK) {
+        slice = bid / nwg;
+        bid -= slice * nwg;
+    }
+    int tm, tn;
+    gd_patch_walk<PM, PN>(gd_xcd_major(bid, nwg), tiles_m, tiles_n, tm, tn);
+    gemm_dense_body<T, SPLITK, FM, I8, OUTL, NCH, 8>(X, Wd, bias, out_v, out_dtype, partial, M, N, K, ldw, k_per_slice, sA, sB, ep,
+                                                     (int64_t)tm * TM, (int64_t)tn << 8, slice);
+}
+
+// Column-balanced grid (round 4): the first `cols_a` tile columns are 32 FNA wide, the remaining tiles_n - cols_a are 32 FNB wide
+// (FNB = FNA - 1), chosen by gemm_dense_nb_plan (gemm_dense.hip) so that tiles_m x tiles_n fills the 256 CUs in whole rounds where uniform
+// 256-wide columns leave a partial last round (4096 x 11008: 688 tiles = 2.69 rounds run as 3; here 8 columns of 256 + 40 of 224 = 768
+// tiles = 3 rounds of which two are 7/8 long).  A workgroup runs the body of its own column's width; a row's summation order does not
+// depend on the tile it is computed in, so the bits equal k_gemm_dense's.  256-row tiles, unsplit, 16-bit.
+template <typename T, int FNA, int FNB>
+__global__ __launch_bounds__(256, 1) void k_gemm_dense_nb(const T *__restrict__ X, const T *__restrict__ Wd, const T *__restrict__ bias,
+                                                          void *__restrict__ out_v, int out_dtype, int64_t M, int64_t N, int64_t K,
+                                                          int64_t ldw, int tiles_n, int cols_a) {
+    const int tiles_m = (int)((M + 255) >> 8);
+    int tm, tn;
+    gd_patch_walk<4, 8>(gd_xcd_major(blockIdx.x, tiles_m * tiles_n), tiles_m, tiles_n, tm, tn);
+    const OutlierEpilogue ep{};
+    if (FNA == FNB || tn < cols_a)
+        gemm_dense_body<T, false, 8, false, 0, 1, FNA>(X, Wd, bias, out_v, out_dtype, nullptr, M, N, K, ldw, K, nullptr, nullptr, ep,
+                                                       (int64_t)tm << 8, (int64_t)tn * (32 * FNA), 0);
+    else
+        gemm_dense_body<T, false, 8, false, 0, 1, FNB>(X, Wd, bias, out_v, out_dtype, nullptr, M, N, K, ldw, K, nullptr, nullptr, ep,
+                                                       (int64_t)tm << 8, (int64_t)cols_a * (32 * FNA) + (int64_t)(tn - cols_a) * (32 * FNB), 0);
 }
 
 }  // namespace mbnb

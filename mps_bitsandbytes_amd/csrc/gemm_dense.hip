@@ -5,6 +5,7 @@
 // Workspace layout (mbnb_matmul_4bit_workspace_bytes reports the sum):
 //   [0, wd_bytes)                    Wd [N, K_weight] in the compute dtype, wd_bytes = N * K_weight * 2 rounded up to 256
 //   [wd_bytes, + slices * M * N * 4) f32 partials of the split-K slices (none when slices == 1)
+#include <cstdio>
 #include "gemm_dense.h"
 #include "gemm_dense128.h"
 #include "gemm_mid.h"
@@ -58,6 +59,70 @@ DensePlan gemm_dense_plan(int64_t M, int64_t N, int64_t K) {
     return best;
 }
 int64_t gemm_dense_slices(int64_t M, int64_t N, int64_t K) { return gemm_dense_plan(M, N, K).slices; }
+
+// Round 4: column-balanced grids for the unsplit 256-row tile (k_gemm_dense_nb, gemm_dense.h).  Uniform 256-wide columns give
+// tiles_m x ceil(N / 256) tiles, and what is left after the last whole round of 256 CUs runs as a partial round: 4096 x 11008 = 688 tiles =
+// 2.69 rounds, 4096 x 13824 = 3.375, 5000 x 5120 = 1.56.  VERDICT r3 priced that partial round as a whole one ("10 % wave quantisation").
+// Measured (tools/exp/nb_rounds.py, profiles/r04_nb_rounds.txt; M = K = 4096, us per round of 256 tiles): a round of 256-wide tiles 90-92,
+// of 224-wide 81-84 (0.90-0.92, not 0.875), of 192-wide 70-72 (0.78, not 0.75): narrower tiles pay the same A pieces, barriers, prologue and
+// epilogue for fewer MFMAs.  And a PARTIAL round of f x 256 tiles costs max(0.66, 0.3 + 0.7 f) of a whole one, not 1: with fewer CUs busy the
+// chip holds a higher clock (DVFS give-back), so uniform columns already sit within 2-6 % of perfect packing -- 4096 x 11008 measures
+// 255.5 us uniform against 259-261 for 8 x 256 + 40 x 224 or 15 x 256 + 32 x 224 (profiles/r04_nb_forced.txt).  What balancing can still
+// win is a small f at few rounds: 5000 x 5120 x 5120 207 -> 193 us (10 x 224 + 15 x 192), 4096 x 13824 x 5120 419 -> 404, 4096 x 14336 x 4096
+// 342 -> 328 (all 224).  The plan therefore prices both forms with the measured costs and takes the balanced grid only where it is
+// predicted to win by 4 %: `cols_a` columns of 32 fna and `cols_b` of 32 (fna - 1), the pair and the column count whose list schedule on
+// 256 CUs -- wide tiles first, the order the grid is walked in -- ends earliest.  Any cut gives every output row the same summation order,
+// so the choice is free of consequences for the bits.
+struct NbPlan { int fna; int cols_a, cols_b; double t_us; };
+// tile cost in us (multi-round rate): prologue + epilogue + k-steps, fitted on tools/exp/nb_rounds.py (K = 4096) and the K = 8192 rows of ab_dense_nb.py
+static double nb_tile_cost(int fn, int64_t nk) {
+    static const double fixed[4] = {6.5, 7.0, 7.5, 7.9}, step[4] = {0.85, 1.008, 1.18, 1.30};      // fn = 5, 6, 7, 8
+    return fixed[fn - 5] + (double)nk * step[fn - 5];
+}
+static double nb_makespan(int64_t na, double ca, int64_t nb, double cb) {
+    const int64_t P = 256, qa = na / P, ra = na % P;
+    double lo = (double)qa * ca, hi = lo + ca;      // after the wide tiles: P - ra CUs are free at lo, ra CUs at hi
+    const int64_t n_lo = P - ra, n_hi = ra;
+    double end = na == 0 ? 0.0 : (ra ? hi : lo);
+    while (nb > 0) {                                  // narrow tiles go to whichever group is free first, a group's worth at a time
+        const bool use_lo = n_hi == 0 || lo <= hi;
+        const int64_t cap = use_lo ? n_lo : n_hi;
+        double &t = use_lo ? lo : hi;
+        t += cb;
+        if (t > end) end = t;
+        nb -= nb < cap ? nb : cap;
+    }
+    return end;
+}
+// fm: the tile the uniform plan (gemm_dense_plan) chose, 8 = 256 x 256 or 4 = 256 (n) x 128 (m) -- the time to beat
+NbPlan gemm_dense_nb_plan(int64_t M, int64_t N, int64_t K, int fm = 8) {
+    const int64_t tiles_m = (M + 255) / 256, U = (N + 31) / 32, nk = K / 64;
+    const int64_t c8 = (U + 7) / 8, tiles8 = tiles_m * c8;
+    // uniform columns: whole rounds + the partial round at its measured discount
+    const double f = (double)(tiles8 % 256) / 256.0, cost8 = nb_tile_cost(8, nk);
+    double uniform_t = cost8 * ((double)(tiles8 / 256) + (f > 0.0 ? (0.3 + 0.7 * f > 0.66 ? 0.3 + 0.7 * f : 0.66) : 0.0));
+    if (fm == 4) {      // 256 x 128 tiles: 0.75 us per k-step, ~5 us of prologue + epilogue, whole rounds (profiles/r02_dense_sweep.txt, r04_ab_dense_nb.txt)
+        const int64_t tiles4 = ((M + 127) / 128) * c8;
+        uniform_t = (double)((tiles4 + 255) / 256) * (5.0 + 0.75 * (double)nk);
+    }
+    NbPlan best{8, (int)c8, 0, uniform_t};
+    if (tiles8 <= 256 || f == 0.0 || tiles_m > 256 || c8 > (1 << 20)) return best;     // less than a round (smaller tiles serve those), or whole rounds already
+    const int64_t span = 256 / tiles_m + 1;          // more than one extra round of columns never helps
+    for (int fna = 8; fna >= 6; fna--) {
+        const int fnb = fna - 1;
+        const int64_t cmin = (U + fna - 1) / fna, cmax = (U + fnb - 1) / fnb;
+        for (int64_t C = cmin; C <= cmax && C <= cmin + span; C++) {
+            int64_t a = U - fnb * C;
+            if (a < 0) a = 0;
+            if (a > C) continue;
+            // mixed widths measure 1-3 % over the sum of their rounds (nb_rounds.py, last columns)
+            const double t = nb_makespan(tiles_m * a, nb_tile_cost(fna, nk), tiles_m * (C - a), nb_tile_cost(fnb, nk)) * ((a > 0 && a < C) ? 1.02 : 1.0);
+            if (t < best.t_us) best = NbPlan{fna, (int)a, (int)(C - a), t};
+        }
+    }
+    if (best.t_us > 0.96 * uniform_t) return NbPlan{8, (int)c8, 0, uniform_t};   // the narrow tiles have to win by a margin
+    return best;
+}
 int64_t gemm_dense_k_per_slice(int64_t K, int64_t slices) {
     const int64_t steps = K / 64;
     return ((steps + slices - 1) / slices) * 64;
@@ -86,6 +151,7 @@ static int launch_gemm_dense_fm(const T *x, const T *wd, const T *bias, void *ou
         if (int rc = ensure_dyn_lds(reinterpret_cast<const void *>(kern), GD_LDS, "matmul_4bit(dense)")) return rc;
         hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), GD_LDS, st, x, wd, bias, out, out_dtype, static_cast<float *>(nullptr),
                            M, N, K, ldw, K, static_cast<const float *>(nullptr), static_cast<const float *>(nullptr), OutlierEpilogue{});
+        set_kernel_name(FM == 8 ? "dense 256x256" : "dense 256x128");
         return check_launch("matmul_4bit(dense)");
     }
     auto kern = k_gemm_dense<T, true, FM>;
@@ -106,6 +172,30 @@ static int launch_gemm_dense_fm(const T *x, const T *wd, const T *bias, void *ou
     return check_launch("matmul_4bit(dense split-K reduce)");
 }
 
+// column-balanced grid of 256-row tiles (k_gemm_dense_nb)
+template <typename T>
+static int launch_gemm_dense_nb(const T *x, const T *wd, const T *bias, void *out, int out_dtype, int64_t M, int64_t N, int64_t K,
+                                int64_t ldw, const NbPlan &pl, hipStream_t st) {
+    const int tiles_n = pl.cols_a + pl.cols_b;
+    const int64_t tiles = ((M + 255) / 256) * tiles_n;
+#define MBNB_NB(FNA, FNB)                                                                                                        \
+    do {                                                                                                                         \
+        auto kern = k_gemm_dense_nb<T, FNA, FNB>;                                                                                \
+        if (int rc = ensure_dyn_lds(reinterpret_cast<const void *>(kern), GD_LDS, "matmul_4bit(dense nb)")) return rc;           \
+        hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), GD_LDS, st, x, wd, bias, out, out_dtype, M, N, K, ldw, tiles_n, \
+                           pl.cols_a);                                                                                           \
+    } while (0)
+    if (pl.fna == 8) MBNB_NB(8, 7);
+    else if (pl.fna == 7) MBNB_NB(7, 6);
+    else MBNB_NB(6, 5);
+#undef MBNB_NB
+    // the plan in the kernel name (mbnb_last_kernel after mbnb_gemm_dense; the matmul paths overwrite it with their own)
+    static thread_local char name[64];
+    snprintf(name, sizeof(name), "dense_nb %dx%d+%dx%d", pl.cols_a, 32 * pl.fna, pl.cols_b, 32 * (pl.fna - 1));
+    set_kernel_name(name);
+    return check_launch("matmul_4bit(dense nb)");
+}
+
 // 128 x 128 tiles (gemm_dense128.h), never split
 template <typename T>
 static int launch_gemm_dense128(const T *x, const T *wd, const T *bias, void *out, int out_dtype, int64_t M, int64_t N, int64_t K,
@@ -117,11 +207,16 @@ static int launch_gemm_dense128(const T *x, const T *wd, const T *bias, void *ou
     return check_launch("matmul_4bit(dense128)");
 }
 
-// fm: 8 / 4 as planned by gemm_dense_plan, 2 = 128 x 128 tiles, 0 = plan here (slices then comes from the caller's workspace check)
+// fm: 8 / 4 as planned by gemm_dense_plan, 2 = 128 x 128 tiles; 9 = 256 x 256 tiles with uniform 256-wide columns (diagnostic: what fm = 8
+// ran before the column-balanced grids of round 4)
 template <typename T>
 static int launch_gemm_dense(const T *x, const T *wd, const T *bias, void *out, int out_dtype, int64_t M, int64_t N, int64_t K,
                              int64_t ldw, float *partial, int64_t slices, int fm, hipStream_t st) {
     if (fm == 2) return launch_gemm_dense128<T>(x, wd, bias, out, out_dtype, M, N, K, ldw, st);
+    if ((fm == 8 || fm == 4) && slices <= 1) {
+        const NbPlan pl = gemm_dense_nb_plan(M, N, K, fm);
+        if (pl.cols_b > 0 || pl.fna != 8) return launch_gemm_dense_nb<T>(x, wd, bias, out, out_dtype, M, N, K, ldw, pl, st);
+    }
     if (fm == 4) return launch_gemm_dense_fm<T, 4>(x, wd, bias, out, out_dtype, M, N, K, ldw, partial, slices, st);
     return launch_gemm_dense_fm<T, 8>(x, wd, bias, out, out_dtype, M, N, K, ldw, partial, slices, st);
 }
@@ -219,9 +314,22 @@ int launch_gemm_i8_dense(const int8_t *A, const int8_t *Bt, const float *sA, con
 }
 
 // diagnostic entry for tools/exp (the dense kernel alone on a caller-made Wd)
+// tile codes (x 128): 128 -> 256 x 128 tiles, 256 -> 256 x 256 tiles with UNIFORM columns (no column balancing), 384 -> 128 x 128 tiles, 0 -> the plan;
+// 640 / 768 / 896 (codes 5 / 6 / 7) -> a FORCED column-balanced grid: `forced_cols_a` columns of 32 (code + 1), the rest of N in columns of 32 code
 int gemm_dense_direct(const void *A, const void *Wd, int dtype, const void *bias, int out_dtype, void *out, int64_t M, int64_t N,
-                      int64_t K, int64_t ldw, float *partial, int64_t slices, int tile_m, hipStream_t st) {
-    const int fm = tile_m == 128 ? 4 : (tile_m == 256 ? 8 : (tile_m == 384 ? 2 : gemm_dense_plan(M, N, K).fm));   // 384: the code of the 128 x 128 tile
+                      int64_t K, int64_t ldw, float *partial, int64_t slices, int tile_m, int forced_cols_a, hipStream_t st) {
+    if (tile_m >= 640) {
+        const int fnb = tile_m / 128, fna = fnb + 1;
+        const int64_t U = (N + 31) / 32;
+        int64_t a = forced_cols_a;
+        if (a * fna > U) a = U / fna;
+        const int64_t b = (U - a * fna + fnb - 1) / fnb;
+        const NbPlan pl{fna, (int)a, (int)b, 0.0};
+        if (dtype == MBNB_F16)
+            return launch_gemm_dense_nb<f16_t>(static_cast<const f16_t *>(A), static_cast<const f16_t *>(Wd), static_cast<const f16_t *>(bias), out, out_dtype, M, N, K, ldw, pl, st);
+        return launch_gemm_dense_nb<bf16_t>(static_cast<const bf16_t *>(A), static_cast<const bf16_t *>(Wd), static_cast<const bf16_t *>(bias), out, out_dtype, M, N, K, ldw, pl, st);
+    }
+    const int fm = tile_m == 128 ? 4 : (tile_m == 256 ? 9 : (tile_m == 384 ? 2 : gemm_dense_plan(M, N, K).fm));
     if (dtype == MBNB_F16)
         return launch_gemm_dense<f16_t>(static_cast<const f16_t *>(A), static_cast<const f16_t *>(Wd), static_cast<const f16_t *>(bias), out,
                                         out_dtype, M, N, K, ldw, partial, slices, fm, st);

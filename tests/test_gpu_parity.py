@@ -1369,3 +1369,81 @@ def test_matmul_decode_once_pass_forms_keep_the_public_kernels_bits(M, N, K, dt,
     y8 = bnb.linear_int8(x, q, sc, b)
     assert _native.last_kernel().startswith("w8a16_dequant+dense")
     assert torch.equal(y8, bnb.functional.linear_dense(x, bnb.dequantize_rowwise(q, sc, dt), b))
+
+
+# --------------------------------------------------------------------------- round-4 additions: column-balanced grids of k_gemm_dense_nb
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K,code,cols_a,dt,odt,with_bias", [
+    (2304, 3584, 256, 7, 0, torch.bfloat16, None, False),          # 16 columns of 224, whole tiles
+    (2304, 3000, 192, 7, 5, torch.float16, None, True),            # 5 x 256 + 8 x 224: the last column 128 wide, ragged M
+    (2500, 2600, 128, 6, 3, torch.bfloat16, torch.float32, True),  # 3 x 224 + 10 x 192 (the last 8 columns wide), f32 output
+    (1300, 4100, 320, 5, 0, torch.float16, None, False),           # 26 columns of 160 (the last 100 wide), five k-steps
+    (4096, 1000, 384, 5, 4, torch.bfloat16, torch.float16, True),  # 4 x 192 + 2 x 160, N % 8 == 0 only
+    (3000, 2041, 256, 6, 2, torch.bfloat16, None, True),           # odd N: the scalar store path of the epilogue
+    (5000, 5120, 512, 7, 10, torch.bfloat16, None, False),         # 20 tile rows (tiles_m % 4 == 0, five patch rows), 500 tiles
+    (3840, 3712, 256, 7, 9, torch.float16, None, False),           # 15 tile rows: a ragged patch row under every patch column
+])
+def test_gemm_dense_column_balanced_grids_keep_the_bits(M, N, K, code, cols_a, dt, odt, with_bias):
+    """k_gemm_dense_nb (round 4, csrc/gemm_dense.h): tile columns 224 / 192 / 160 wide, alone or behind wider ones, walked in ragged XCD patches --
+    forced through the diagnostic tile codes of mbnb_gemm_dense.  Every output element is written exactly as the uniform 256 x 256 tiles
+    write it (same B bits, same summation order per row): torch.equal on NaN-prefilled outputs, f16 / bf16, bias, f32 and 16-bit outputs,
+    ragged M and N; and a float64 product of the same operands."""
+    lib = _native.lib()
+    x = synthetic.normal((M, K), dt, seed=811).to(DEV)
+    w = synthetic.normal((N, K), dt, seed=812, std=0.05).to(DEV)
+    bias = synthetic.normal((N,), dt, seed=813).to(DEV) if with_bias else None
+    odt = odt or dt
+    code_dt, code_o = _native.DTYPE_CODE[dt], _native.DTYPE_CODE[odt]
+
+    def run(sel):
+        out = torch.full((M, N), float("nan"), dtype=odt, device=DEV)
+        rc = lib.mbnb_gemm_dense(x.data_ptr(), w.data_ptr(), code_dt, None if bias is None else bias.data_ptr(), code_o, out.data_ptr(), M, N, K, K,
+                                 None, 0, 1 | sel, _native.stream_ptr(DEV))
+        assert rc == 0, lib.mbnb_last_error()
+        return out, _native.last_kernel()
+
+    y_u, name_u = run(2 << 8)
+    y_b, name_b = run((code << 8) | (cols_a << 16))
+    assert name_u == "dense 256x256" and name_b.startswith("dense_nb "), (name_u, name_b)
+    assert f"{cols_a}x{32 * (code + 1)}+" in name_b and name_b.endswith(f"x{32 * code}")
+    assert bool(torch.isfinite(y_b.float()).all()), "an output element was never written"
+    assert torch.equal(y_u, y_b), f"{name_b} differs from the uniform tiles"
+    rows = torch.arange(0, M, max(1, M // 24))[:24]
+    ref = x[rows.to(DEV)].double() @ w.double().t() + (0 if bias is None else bias.double())
+    assert rel_fro(y_b[rows.to(DEV)].cpu(), ref.cpu()) <= 1.5 * TOL[dt]     # against the EXACT product: the output's own rounding is inside
+
+
+@pytest.mark.gpu
+def test_matmul_4bit_takes_the_balanced_grid_where_its_plan_says_so():
+    """4096 x 6144 x 4096 (24 columns of 256 = 384 tiles = 1.5 rounds of 256 CUs): the plan cuts N into 32 columns of 192 (two whole rounds of
+    smaller tiles, tools/exp/ab_dense_nb.py) -- through matmul_4bit the result equals the fused kernel's bits (k_gemm_fused4: same B bits,
+    same summation order) and the oracle on a row sample; BASELINE configs[2] (11008 wide) keeps its uniform columns."""
+    lib = _native.lib()
+    M, N, K, dt = 4096, 6144, 4096, torch.bfloat16
+    W = synthetic.normal((N, K), dt, seed=821, std=0.02)
+    X = synthetic.normal((M, K), dt, seed=822).to(DEV)
+    packed, st = bnb.quantize_nf4(W.to(DEV), compress_statistics=True)
+    wd = bnb.dequantize_4bit(packed, st)
+    out = torch.empty(M, N, dtype=dt, device=DEV)
+    code = _native.DTYPE_CODE[dt]
+    assert lib.mbnb_gemm_dense(X.data_ptr(), wd.data_ptr(), code, None, code, out.data_ptr(), M, N, K, K, None, 0, 0, _native.stream_ptr(DEV)) == 0
+    assert _native.last_kernel().startswith("dense_nb "), _native.last_kernel()
+    y = bnb.matmul_4bit(X, packed, st)
+    assert _native.last_kernel() == "dequant+dense"
+    assert torch.equal(y, out)
+    bnb.functional.DECODE_ONCE = False
+    try:
+        yf = bnb.matmul_4bit(X, packed, st)
+        assert _native.last_kernel() == "mfma256f"
+    finally:
+        bnb.functional.DECODE_ONCE = True
+    assert torch.equal(y, yf)
+    rows = torch.arange(5, M, 173)
+    op, oa, os2 = oracle.quantize_4bit(W, 64, "nf4", True)
+    ref = oracle.matmul_4bit(X[rows.to(DEV)].cpu(), op, oa, (N, K), 64, "nf4", dt, None, None, os2)
+    assert rel_fro(y[rows.to(DEV)].cpu(), ref) <= TOL[dt]
+    out2 = torch.empty(M, 11008, dtype=dt, device=DEV)
+    w2 = synthetic.normal((11008, 256), dt, seed=823).to(DEV)
+    x2 = synthetic.normal((M, 256), dt, seed=824).to(DEV)
+    assert lib.mbnb_gemm_dense(x2.data_ptr(), w2.data_ptr(), code, None, code, out2.data_ptr(), M, 11008, 256, 256, None, 0, 0, _native.stream_ptr(DEV)) == 0
+    assert _native.last_kernel() == "dense 256x256"
