@@ -207,8 +207,8 @@ static int launch_gemm_dense128(const T *x, const T *wd, const T *bias, void *ou
     return check_launch("matmul_4bit(dense128)");
 }
 
-// fm: 8 / 4 as planned by gemm_dense_plan, 2 = 128 x 128 tiles; 9 = 256 x 256 tiles with uniform 256-wide columns (diagnostic: what fm = 8
-// ran before the column-balanced grids of round 4)
+// fm: 8 / 4 as planned by gemm_dense_plan (the column-balanced grid where its plan beats them), 2 = 128 x 128 tiles; 9 / 10 = 256 x 256 / 256 x 128
+// tiles in uniform 256-wide columns, no balancing (diagnostic: what fm = 8 / 4 ran before round 4)
 template <typename T>
 static int launch_gemm_dense(const T *x, const T *wd, const T *bias, void *out, int out_dtype, int64_t M, int64_t N, int64_t K,
                              int64_t ldw, float *partial, int64_t slices, int fm, hipStream_t st) {
@@ -217,7 +217,7 @@ static int launch_gemm_dense(const T *x, const T *wd, const T *bias, void *out, 
         const NbPlan pl = gemm_dense_nb_plan(M, N, K, fm);
         if (pl.cols_b > 0 || pl.fna != 8) return launch_gemm_dense_nb<T>(x, wd, bias, out, out_dtype, M, N, K, ldw, pl, st);
     }
-    if (fm == 4) return launch_gemm_dense_fm<T, 4>(x, wd, bias, out, out_dtype, M, N, K, ldw, partial, slices, st);
+    if (fm == 4 || fm == 10) return launch_gemm_dense_fm<T, 4>(x, wd, bias, out, out_dtype, M, N, K, ldw, partial, slices, st);
     return launch_gemm_dense_fm<T, 8>(x, wd, bias, out, out_dtype, M, N, K, ldw, partial, slices, st);
 }
 
@@ -329,7 +329,7 @@ int gemm_dense_direct(const void *A, const void *Wd, int dtype, const void *bias
             return launch_gemm_dense_nb<f16_t>(static_cast<const f16_t *>(A), static_cast<const f16_t *>(Wd), static_cast<const f16_t *>(bias), out, out_dtype, M, N, K, ldw, pl, st);
         return launch_gemm_dense_nb<bf16_t>(static_cast<const bf16_t *>(A), static_cast<const bf16_t *>(Wd), static_cast<const bf16_t *>(bias), out, out_dtype, M, N, K, ldw, pl, st);
     }
-    const int fm = tile_m == 128 ? 4 : (tile_m == 256 ? 9 : (tile_m == 384 ? 2 : gemm_dense_plan(M, N, K).fm));
+    const int fm = tile_m == 128 ? 10 : (tile_m == 256 ? 9 : (tile_m == 384 ? 2 : gemm_dense_plan(M, N, K).fm));   // 9 / 10: that tile in uniform columns, no balancing
     if (dtype == MBNB_F16)
         return launch_gemm_dense<f16_t>(static_cast<const f16_t *>(A), static_cast<const f16_t *>(Wd), static_cast<const f16_t *>(bias), out,
                                         out_dtype, M, N, K, ldw, partial, slices, fm, st);

@@ -50,30 +50,21 @@ __global__ __launch_bounds__(256, 1) void k_gemm_i8_inplace(const int8_t *__rest
     if (tid == 0) g_gi8_stamps[8 + 4 * blockIdx.x + 0] = wall_clock64();
 #endif
 
-    const int64_t tiles_m = (M + 255) >> 8, tiles_n = (N + 255) >> 8;
-    const int64_t nwg = tiles_m * tiles_n;
-    int64_t bid = blockIdx.x;
-    {
-        const int64_t q = nwg / 8, r = nwg % 8, xcd = bid % 8;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
-    }
-    int64_t tm, tn;
-    if ((tiles_m % 4 == 0) && (tiles_n % 8 == 0)) {
-        const int64_t patch = bid >> 5, within = bid & 31;
-        const int64_t patches_m = tiles_m >> 2;
-        tm = (patch % patches_m) * 4 + (within & 3);
-        tn = (patch / patches_m) * 8 + (within >> 2);
-    } else {
-        tm = bid % tiles_m;
-        tn = bid / tiles_m;
-    }
-    const int64_t m0 = tm << 8, n0 = tn << 8;
+    // tile -> workgroup: the walk of k_gemm_dense (gemm_dense.h, round 4): pseudo-patches of 32 tiles dealt to the XCDs in turn, 4 x 8 patches
+    // that are ragged at the grid's edges (round 3 fell back to a column-major order whenever tiles_m % 4 or tiles_n % 8 was not 0)
+    const int tiles_m = (int)((M + 255) >> 8), tiles_n = (int)((N + 255) >> 8);
+    int tm, tn;
+    gd_patch_walk<4, 8>(gd_xcd_major(blockIdx.x, tiles_m * tiles_n), tiles_m, tiles_n, tm, tn);
+    const int64_t m0 = (int64_t)tm << 8, n0 = (int64_t)tn << 8;
     const int nk = (int)(K >> 7);
 
     // ---- LDS-DMA.  A: wave w moves pieces 8w..8w+7 of 8 rows x 128 B (row in the per-lane offset, k in the scalar offset,
     // rows past M read as zeros).  B: wave w moves k-rows 32w..32w+31 as 8 pieces of 4 rows x 256 B; the k-row inside the tile
-    // and the (swizzled) column chunk in the per-lane offset, the tile's k position (k0 * N) in the scalar offset; the
-    // descriptor ends with the matrix, so a chunk past the last row's end reads as zeros (columns past N are never stored).
+    // and the (swizzled) column chunk in the per-lane offset, the tile's k position (k0 * N) in the scalar offset.  The
+    // descriptor's range check covers the per-lane offset only (not the scalar one), so it cannot stop a chunk of the last tile column
+    // that lies past N: such a chunk would read the NEXT k-row's first columns (harmless: those columns are never stored) and, on
+    // the tile's last k-rows, up to 240 bytes past the end of B (a fault when B ends on a page boundary).  Those lanes get a
+    // per-lane offset beyond num_records instead: the range check zero-fills them and nothing outside B is touched.
     typedef int i32x4_t __attribute__((ext_vector_type(4)));
     i32x4_t rs_a, rs_b;
     {
@@ -89,7 +80,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_i8_inplace(const int8_t *__rest
         voff_a[pl] = (int)(row * K) + 16 * ((lane & 7) ^ ((row >> 1) & 7)) - GD_M0_GROUP * (pl & 3) * 1024;
         const int krow = 32 * wave + 4 * pl + (lane >> 4);
         const int c = (lane & 15) ^ (((krow & 7) << 1) | ((krow >> 4) & 1));
-        voff_b[pl] = (int)(krow * N) + 16 * c - GD_M0_GROUP * (pl & 3) * 1024;
+        voff_b[pl] = (n0 + 16 * c < N ? (int)(krow * N) + 16 * c : 0x7FFF0000) - GD_M0_GROUP * (pl & 3) * 1024;
     }
     const int kstep_b = (int)(128 * N);     // bytes of B between two k-steps
     const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)smem;

@@ -6,7 +6,7 @@ namespace mbnb {
 
 bool gemm_i8_inplace_shape(const int8_t *A, const int8_t *B, int64_t M, int64_t N, int64_t K) {
     return (K % 128 == 0) && K >= 256 && (N % 16 == 0) && N >= 256 && ((M + 255) / 256) * ((N + 255) / 256) >= 96 && 256 * K < ((int64_t)1 << 31) &&
-           K * N < ((int64_t)1 << 31) && ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0;
+           K * N < ((int64_t)1 << 31) - (1 << 17) &&   /* the zero-fill offset of gemm_i8_inplace.h (0x7FFF0000 - 3072) lies beyond num_records */ ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0;
 }
 
 int launch_gemm_i8_inplace(const int8_t *A, const int8_t *B, const float *sA, const float *sB, int64_t M, int64_t N, int64_t K,

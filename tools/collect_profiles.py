@@ -116,5 +116,16 @@ if "FETCH_SIZE" in res:
         if v is not None:
             out[key] = v
             out[key + "_algorithmic"] = alg
+    # where these counters come from: bench.py repeats it next to every `traffic` figure so that a stale file is visible in the line
+    import datetime, subprocess
+    try:
+        commit = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, check=True).stdout.strip()
+        dirty = bool(subprocess.run(["git", "-C", root, "status", "--porcelain", "--", "mps_bitsandbytes_amd", "bench.py"], capture_output=True, text=True).stdout.strip())
+    except Exception:
+        commit, dirty = "unknown", False
+    mt = max((os.path.getmtime(f) for f in glob.glob(os.path.join(src, f"{tag}_fetch", "*", "*counter_collection.csv"))), default=None)
+    out["_source"] = {"tag": tag, "commit": commit + ("+uncommitted" if dirty else ""),
+                      "date": datetime.datetime.utcfromtimestamp(mt).strftime("%Y-%m-%d %H:%M UTC") if mt else "unknown",
+                      "recipe": "tools/profile_round.sh " + tag + " on an MI355X box, condensed by tools/collect_profiles.py"}
     json.dump(out, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
     print(json.dumps({k: v for k, v in out.items() if k != "counters"}, indent=1))

@@ -42,8 +42,7 @@ def t_us(g):
     return e0.elapsed_time(e1) / 20 * 1e3
 
 
-print(f"{'M x N x K':>22s}  {'plan':>22s}  equal   uniform us   256x128* us   plan us   gain vs best other   TFLOP/s (plan)  frac", flush=True)
-print("(* tile code 1 consults the balanced plan as well: where `plan` is dense_nb that column ran the balanced grid too; the 256 x 128 tiles proper are in the rows whose plan is 'dense 256x256')", flush=True)
+print(f"{'M x N x K':>22s}  {'plan':>22s}  equal   uniform us   256x128 us   plan us   gain vs best other   TFLOP/s (plan)  frac", flush=True)
 for (M, N, K) in shapes:
     gen = torch.Generator(device=dev); gen.manual_seed(M + N + K)
     x = torch.randn(M, K, generator=gen, device=dev).to(dt)
