@@ -23,6 +23,11 @@
 
 namespace mbnb {
 
+#ifndef GV_ABL
+#define GV_ABL 0    // diagnostic builds (tools/exp/abl_gemv.py; timing only, results are wrong): 1 no table lookups / products (the packed dword is the
+                    // operand), 2 no activation reads from LDS, 4 no decode loop at all (loads, wait, reduce), 8 no weight / absmax loads either
+#endif
+
 __device__ __forceinline__ float dpp_wave_sum(float v) {
     // row_shr 1, 2, 3 -> each lane holds the sum of up to 4 predecessors in its row of 16; then the classic row reduction
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xF, 0xF, true));   // row_shr:1
@@ -76,6 +81,11 @@ __global__ __launch_bounds__(256) void k_gemv4_lean(const T *__restrict__ X, con
 #pragma unroll
     for (int u = 0; u < KU; u++) {
         // lane l: packed bytes 16 l .. + 15 of chunk u (k = 2048 u + 32 l .. + 31), one absmax (block 32 u + l / 2)
+#if GV_ABL & 8
+        wq[u] = u32x4{(uint32_t)lane, 1u, 2u, 3u};
+        a[u] = 1.0f;
+        continue;
+#endif
         wq[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, lane * 16, u * 1024, 2));    // aux 2: nt
         if constexpr (!NESTED) {
             a[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_m, (lane >> 1) * 4, u * 128, 0));
@@ -99,12 +109,25 @@ __global__ __launch_bounds__(256) void k_gemv4_lean(const T *__restrict__ X, con
 
     float acc = 0.0f;
     const char *lutb = reinterpret_cast<const char *>(lut);
+#if GV_ABL & 4
+#pragma unroll
+    for (int u = 0; u < KU; u++) acc += __builtin_bit_cast(float, wq[u][0] ^ wq[u][1] ^ wq[u][2] ^ wq[u][3]) * a[u];
+#else
 #pragma unroll
     for (int u = 0; u < KU; u++) {
 #pragma unroll
         for (int c = 0; c < 4; c++) {
             const uint32_t w = wq[u][c];
+#if GV_ABL & 2
+            const u32x4 xq = u32x4{w, w + 1, w + 2, w + 3};
+#else
             const u32x4 xq = *reinterpret_cast<const u32x4 *>(xs + (2048 * u + 32 * lane + 8 * c) * 2);
+#endif
+#if GV_ABL & 1
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc = Dot2<T>::run(w + j, xq[j], acc);
+            continue;
+#endif
             const uint32_t wo = w & 0xF0F0F0F0u;
             const uint32_t we = (w << 2) & 0x3C3C3C3Cu;
 #pragma unroll
@@ -116,6 +139,7 @@ __global__ __launch_bounds__(256) void k_gemv4_lean(const T *__restrict__ X, con
             }
         }
     }
+#endif
     const float s = dpp_wave_sum(acc);
     if (lane == 63 && live) {
         const float v = s + (bias ? to_f32(bias[n]) : 0.0f);
