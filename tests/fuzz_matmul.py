@@ -28,7 +28,7 @@ def draw(rng):
         K = 64 * rng.randint(1, 48)
     else:
         K = 8 * rng.randint(4, 200)
-    N = rng.choice([64, 256, 512, 1000, 1024, 2048, 4096, 520, 777, 11008 // 4, 4104]) if rng.random() < 0.7 else rng.randint(16, 3000)
+    N = rng.choice([64, 256, 512, 1000, 1024, 2048, 4096, 520, 777, 11008 // 4, 4104, 5120, 6144]) if rng.random() < 0.7 else rng.randint(16, 3000)   # 5120 / 6144 x >= 3841 rows: the column-balanced grids of round 4
     while M * N * K > 6e9:      # the oracle's share of the run
         M = max(1, M // 2)
     bs = rng.choice([64] * 5 + [32, 128, 256, 2048])
