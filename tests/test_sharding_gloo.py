@@ -47,8 +47,17 @@ def _worker(rank, world, port, M, return_dict):
             ok = True
             for _ in range(3):
                 view = cg.step(X[s:e])
+                # round 4: until its gather has been waited for, every chunk's shard stays referenced next to its work handle
+                held = [p for b in cg.pending for p in b]
+                ok = ok and len(held) == 2 and all(isinstance(p, tuple) and p[1].shape == ((e - s) // 2, N) and p[1].is_contiguous() for p in held)
                 cg.finish()
+                ok = ok and cg.pending == [[], []]
                 ok = ok and bool(torch.equal(view.reshape(M, N), ref))
+            # two steps in flight: the buffer of step i is only rewritten after step i's gathers were waited for
+            v1 = cg.step(X[s:e]); v2 = cg.step(X[s:e])
+            ok = ok and sum(len(b) for b in cg.pending) == 4
+            cg.finish()
+            ok = ok and bool(torch.equal(v1.reshape(M, N), ref)) and bool(torch.equal(v2.reshape(M, N), ref))
             return_dict[f"chunked{rank}"] = ok
     finally:
         dist.destroy_process_group()
