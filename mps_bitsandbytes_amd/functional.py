@@ -21,7 +21,7 @@ import torch
 from torch import Tensor
 
 from . import _native
-from ._native import AbsmaxDesc, check, dtype_code, ptr, stream_ptr
+from ._native import AbsmaxDesc, check, dtype_code, ptr, stream_ptr, on_device
 
 # ============================================================================= codebooks
 # reference: functional.py:21-32
@@ -69,6 +69,13 @@ _warned: set = set()
 # N x K_weight x 2 bytes per call from torch's caching allocator (32 MB for a 4096^2 layer, ~1 GB for a 128k x 4096 head).
 DECODE_ONCE = True
 MATMUL_FUSED_ONLY = 1   # include/mbnb_hip.h MBNB_MATMUL_FUSED_ONLY: the flags word of mbnb_matmul_4bit / mbnb_linear_int8 / mbnb_linear_fp8
+
+
+def _as(t: Tensor, dtype: torch.dtype, device=None) -> Tensor:
+    """`t.to(device, dtype).contiguous()` that dispatches nothing when `t` already is what is asked for"""
+    if t.dtype != dtype or (device is not None and t.device != device):
+        t = t.to(device=device if device is not None else t.device, dtype=dtype)
+    return t if t.is_contiguous() else t.contiguous()
 
 
 def _warn_once(key: str, message: str) -> None:
@@ -153,10 +160,14 @@ def _absmax_desc(absmax: Tensor, state2: Optional[QuantState], keep: list) -> Ab
         if (absmax.dtype == torch.int8 and state2.state2 is None and state2.dtype == torch.float32
                 and state2.absmax.dtype == torch.float32):
             bs2 = int(state2.blocksize)
-            q = absmax.contiguous()
+            q = absmax if absmax.is_contiguous() else absmax.contiguous()
             # the second-level absmax follows the first level's device (a QuantState built by from_dict() defaults to
             # 'cpu'; handing the kernel a host pointer would be a GPU fault where the reference raises a device mismatch)
-            a2 = state2.absmax.to(device=absmax.device, dtype=torch.float32).contiguous()
+            a2 = state2.absmax
+            if a2.device != absmax.device:
+                a2 = a2.to(device=absmax.device)
+            if not a2.is_contiguous():
+                a2 = a2.contiguous()
             need2 = (q.numel() + bs2 - 1) // bs2 if bs2 > 0 else -1
             if bs2 <= 0 or a2.numel() < need2:
                 raise ValueError(f"state2.absmax has {a2.numel()} elements, expected {need2} "
@@ -165,7 +176,11 @@ def _absmax_desc(absmax: Tensor, state2: Optional[QuantState], keep: list) -> Ab
             return AbsmaxDesc(None, q.data_ptr(), a2.data_ptr(), bs2)
         state2 = _state_on(state2, absmax.device)
         absmax = dequantize_blockwise(absmax, state2)
-    a = absmax.to(torch.float32).contiguous()
+    a = absmax
+    if a.dtype != torch.float32:
+        a = a.to(torch.float32)
+    if not a.is_contiguous():
+        a = a.contiguous()
     keep.append(a)
     return AbsmaxDesc(a.data_ptr(), None, None, 0)
 
@@ -248,7 +263,7 @@ def quantize_4bit(
     fused_dq = compress_statistics and absmax_in is None and 8 <= blocksize <= 512 and nblocks > 0
     absmax_t = None
     state2 = None
-    with torch.cuda.device(A.device):
+    with on_device(A.device):
         if fused_dq:
             codes = torch.empty(nblocks, dtype=torch.int8, device=A.device)
             absmax2 = torch.empty((nblocks + 255) // 256, dtype=torch.float32, device=A.device)
@@ -341,7 +356,7 @@ def dequantize_4bit(
     direct = (out is not None and out.dtype == dtype and out.is_contiguous() and out.numel() == rows * cols
               and out.device == A.device)
     result = out if direct else torch.empty(out_shape, dtype=dtype, device=A.device)
-    with torch.cuda.device(A.device):
+    with on_device(A.device):
         check(_native.lib().mbnb_dequantize_4bit(
             ptr(A), ctypes.byref(desc), rows, cols, cols_padded, int(blocksize), _native.QUANT_CODE[quant_type],
             dtype_code(dtype, "dequantize_4bit"), ptr(result), stream_ptr(A.device)), "dequantize_4bit")
@@ -401,7 +416,7 @@ def quantize_blockwise(
         absmax_in = absmax.to(device=A.device, dtype=torch.float32).contiguous().view(-1)
     q = torch.empty(numel, dtype=torch.int8, device=A.device)
     absmax_out = torch.empty(nblocks, dtype=torch.float32, device=A.device)
-    with torch.cuda.device(A.device):
+    with on_device(A.device):
         check(_native.lib().mbnb_quantize_blockwise(
             ptr(A), dcode, numel, int(blocksize), ptr(absmax_in), ptr(q), ptr(absmax_out),
             stream_ptr(A.device)), "quantize_blockwise")
@@ -453,7 +468,7 @@ def dequantize_blockwise(
     numel = q.numel()
     am = absmax.to(device=A.device, dtype=torch.float32).contiguous()
     result = torch.empty(numel, dtype=dtype, device=A.device)
-    with torch.cuda.device(A.device):
+    with on_device(A.device):
         check(_native.lib().mbnb_dequantize_blockwise(
             ptr(q), numel, ptr(am), int(blocksize), dtype_code(dtype, "dequantize_blockwise"), ptr(result),
             stream_ptr(A.device)), "dequantize_blockwise")
@@ -475,7 +490,7 @@ def quantize_rowwise(tensor: Tensor) -> Tuple[Tensor, Tensor]:
     rows = t.numel() // cols if cols else 0
     q = torch.empty(t.shape, dtype=torch.int8, device=t.device)
     scales = torch.empty(rows, dtype=torch.float32, device=t.device)
-    with torch.cuda.device(t.device):
+    with on_device(t.device):
         check(_native.lib().mbnb_quantize_rowwise(
             ptr(t), dtype_code(t.dtype, "quantize_rowwise"), rows, cols, ptr(q), ptr(scales),
             stream_ptr(t.device)), "quantize_rowwise")
@@ -493,7 +508,7 @@ def dequantize_rowwise(quantized: Tensor, scales: Tensor, dtype: torch.dtype = t
     if s.numel() != rows:
         raise ValueError(f"scales has {s.numel()} elements, expected {rows}")
     out = torch.empty(q.shape, dtype=dtype, device=q.device)
-    with torch.cuda.device(q.device):
+    with on_device(q.device):
         check(_native.lib().mbnb_dequantize_rowwise(
             ptr(q), ptr(s), rows, cols, dtype_code(dtype, "dequantize_rowwise"), ptr(out),
             stream_ptr(q.device)), "dequantize_rowwise")
@@ -535,12 +550,22 @@ def matmul_4bit(
     w_code = dtype_code(w_dtype, "matmul_4bit")
 
     orig_shape = A.shape
-    A2 = A.reshape(-1, K).to(w_dtype).contiguous()   # reference: A.to(weight.dtype), functional.py:764
+    # reference: A.to(weight.dtype), functional.py:764.  (No-op conversions are skipped by hand: at M = 1 the kernel takes 5 us and every
+    # dispatched torch call costs ~1 us of host time, tools/host_overhead.py.)
+    A2 = A if A.dim() == 2 else A.reshape(-1, K)
+    if A2.dtype != w_dtype:
+        A2 = A2.to(w_dtype)
+    if not A2.is_contiguous():
+        A2 = A2.contiguous()
     M = A2.shape[0]
     bias_w = None
     if bias is not None:
-        bias_w = bias.to(device=A.device, dtype=w_dtype).contiguous()  # functional.py:765-766
-    packed = B.contiguous()
+        bias_w = bias   # functional.py:765-766
+        if bias_w.dtype != w_dtype or bias_w.device != A.device:
+            bias_w = bias_w.to(device=A.device, dtype=w_dtype)
+        if not bias_w.is_contiguous():
+            bias_w = bias_w.contiguous()
+    packed = B if B.is_contiguous() else B.contiguous()
     if packed.dtype != torch.uint8:
         packed = packed.to(torch.uint8)
     if packed.numel() * 2 < N * K_weight:
@@ -558,22 +583,37 @@ def matmul_4bit(
     out_dtype = compute_dtype if compute_dtype in _native.DTYPE_CODE else w_dtype
     out = torch.empty(M, N, dtype=out_dtype, device=A.device)
     keep: list = []
-    desc = _absmax_desc(quant_state.absmax.to(A.device), quant_state.state2, keep)
+    am = quant_state.absmax
+    desc = _absmax_desc(am if am.device == A.device else am.to(A.device), quant_state.state2, keep)
     # The library's scratch (0 bytes = none needed for this shape): mid-sized M leaves too few output tiles for 256 CUs and
     # K is split over f32 partials; large M (>= 256 rows, >= 1.5 M outputs) decodes the weight ONCE into it (N x K_weight in the weight dtype) and
     # runs a dense MFMA GEMM instead of re-decoding every weight tile per 256 rows.  torch's caching allocator makes the
     # allocation a pointer bump; the memory goes back to the pool on return.
     flags = 0 if DECODE_ONCE else MATMUL_FUSED_ONLY
-    ws_bytes = int(_native.lib().mbnb_matmul_4bit_workspace_bytes(M, N, K, K_weight, w_code, flags))
+    ws_bytes = _matmul4_ws_bytes(M, N, K, K_weight, w_code, flags)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=A.device) if ws_bytes > 0 else None
-    with torch.cuda.device(A.device):
+    with on_device(A.device):
         check(_native.lib().mbnb_matmul_4bit(
             ptr(A2), M, K, ptr(packed), ctypes.byref(desc), N, K_weight, int(blocksize),
             _native.QUANT_CODE[quant_state.quant_type], w_code, ptr(bias_w), _native.DTYPE_CODE[out_dtype],
             ptr(out), ptr(ws), ws_bytes, flags, stream_ptr(A.device)), "matmul_4bit")
     if out_dtype != compute_dtype:
         out = out.to(compute_dtype)
-    return out.reshape(*orig_shape[:-1], N)
+    return out if len(orig_shape) == 2 else out.reshape(*orig_shape[:-1], N)
+
+
+_WS_CACHE: dict = {}
+
+
+def _matmul4_ws_bytes(M: int, N: int, K: int, K_weight: int, w_code: int, flags: int) -> int:
+    """mbnb_matmul_4bit_workspace_bytes, memoised: a pure function of its arguments (a decode loop asks the same question for every token)."""
+    key = (M, N, K, K_weight, w_code, flags)
+    v = _WS_CACHE.get(key)
+    if v is None:
+        if len(_WS_CACHE) > 4096:
+            _WS_CACHE.clear()
+        v = _WS_CACHE[key] = int(_native.lib().mbnb_matmul_4bit_workspace_bytes(M, N, K, K_weight, w_code, flags))
+    return v
 
 
 def matmul_nf4(input: Tensor, weight_packed: Tensor, weight_state: QuantState,
@@ -618,7 +658,7 @@ def matmul_int8(A: Tensor, B: Tensor, A_scales: Tensor, B_scales: Tensor,
     if not DECODE_ONCE and K % 128 == 0 and N % 16 == 0 and ((M + 255) // 256) * ((N + 255) // 256) >= 96:
         ws_bytes = 0      # large aligned problems without scratch: B read in place as [K, N] (no transpose)
     workspace = torch.empty(ws_bytes, dtype=torch.int8, device=A.device) if ws_bytes > 0 else None
-    with torch.cuda.device(A.device):
+    with on_device(A.device):
         check(_native.lib().mbnb_matmul_int8(
             ptr(A), ptr(B), ptr(sa), ptr(sb), M, N, K, _native.DTYPE_CODE[out_dtype], ptr(out), ptr(workspace), ws_bytes,
             stream_ptr(A.device)), "matmul_int8")
@@ -640,19 +680,19 @@ def linear_int8(input: Tensor, weight_int8: Tensor, weight_scales: Tensor, bias:
     N, K = weight_int8.shape
     if input.shape[-1] != K:
         raise RuntimeError(f"linear_int8: input width {input.shape[-1]} does not match weight {tuple(weight_int8.shape)}")
-    x = input.reshape(-1, K).to(dtype).contiguous()
+    x = _as(input if input.dim() == 2 else input.reshape(-1, K), dtype)      # (no-op conversions skipped: ~1 us of host time each)
     M = x.shape[0]
-    w = weight_int8.contiguous()
-    s = weight_scales.to(device=x.device, dtype=torch.float32).contiguous()
-    b = None if bias is None else bias.to(device=x.device, dtype=dtype).contiguous()
+    w = weight_int8 if weight_int8.is_contiguous() else weight_int8.contiguous()
+    s = _as(weight_scales, torch.float32, x.device)
+    b = None if bias is None else _as(bias, dtype, x.device)
     out = torch.empty(M, N, dtype=dtype, device=x.device)
     flags = 0 if DECODE_ONCE else MATMUL_FUSED_ONLY
     ws_bytes = int(_native.lib().mbnb_linear_int8_workspace_bytes(M, N, K, flags)) if M > 16 else 0   # split-K partials / the dequantised weight
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes > 0 else None
-    with torch.cuda.device(x.device):
+    with on_device(x.device):
         check(_native.lib().mbnb_linear_int8(ptr(x), dcode, M, K, ptr(w), ptr(s), N, ptr(b), ptr(out), ptr(ws), ws_bytes,
                                              flags, stream_ptr(x.device)), "linear_int8")
-    return out.reshape(*input.shape[:-1], N)
+    return out if input.dim() == 2 else out.reshape(*input.shape[:-1], N)
 
 
 def linear_dense(input: Tensor, weight: Tensor, bias: Optional[Tensor] = None) -> Tensor:
@@ -676,7 +716,7 @@ def linear_dense(input: Tensor, weight: Tensor, bias: Optional[Tensor] = None) -
     out = torch.empty(M, N, dtype=dtype, device=x.device)
     ws_bytes = int(_native.lib().mbnb_gemm_dense_workspace_bytes(M, N, K))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes > 0 else None
-    with torch.cuda.device(x.device):
+    with on_device(x.device):
         check(_native.lib().mbnb_gemm_dense(ptr(x), ptr(w), dcode, ptr(b), dcode, ptr(out), M, N, K, K, ptr(ws), ws_bytes, 0,
                                             stream_ptr(x.device)), "linear_dense")
     return out.reshape(*input.shape[:-1], N)
@@ -702,7 +742,7 @@ def quantize_fp8_e4m3(tensor: Tensor) -> Tuple[Tensor, Tensor]:
     rows, cols = A.shape
     out = torch.empty(rows, cols, dtype=torch.uint8, device=A.device)
     scales = torch.empty(rows, dtype=torch.float32, device=A.device)
-    with torch.cuda.device(A.device):
+    with on_device(A.device):
         check(_native.lib().mbnb_quantize_fp8_e4m3(ptr(A), dtype_code(A.dtype, "quantize_fp8_e4m3"), rows, cols, ptr(out),
                                                    ptr(scales), stream_ptr(A.device)), "quantize_fp8_e4m3")
     return out, scales
@@ -715,7 +755,7 @@ def dequantize_fp8_e4m3(quantized: Tensor, scales: Tensor, dtype: torch.dtype = 
     rows, cols = q.shape
     s = scales.to(device=q.device, dtype=torch.float32).contiguous()
     out = torch.empty(rows, cols, dtype=dtype, device=q.device)
-    with torch.cuda.device(q.device):
+    with on_device(q.device):
         check(_native.lib().mbnb_dequantize_fp8_e4m3(ptr(q), ptr(s), rows, cols, dtype_code(dtype, "dequantize_fp8_e4m3"),
                                                      ptr(out), stream_ptr(q.device)), "dequantize_fp8_e4m3")
     return out
@@ -745,7 +785,7 @@ def matmul_fp8_e4m3(input: Tensor, weight: Tensor, weight_scales: Tensor, bias: 
     flags = 0 if DECODE_ONCE else MATMUL_FUSED_ONLY
     ws_bytes = int(_native.lib().mbnb_linear_int8_workspace_bytes(M, N, K, flags)) if M > 16 else 0
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x2.device) if ws_bytes > 0 else None
-    with torch.cuda.device(x2.device):
+    with on_device(x2.device):
         check(_native.lib().mbnb_linear_fp8(ptr(x2), dcode, M, K, ptr(w), ptr(s), N, ptr(b), ptr(out), ptr(ws), ws_bytes,
                                             flags, stream_ptr(x2.device)), "matmul_fp8_e4m3")
     out = out.reshape(*lead, N)
@@ -773,7 +813,7 @@ def embedding_4bit(input: Tensor, weight_packed: Tensor, weight_absmax: Tensor, 
     out = torch.empty(idx.numel(), embedding_dim, dtype=dtype, device=dev)
     wp = weight_packed.contiguous()
     wa = weight_absmax.to(device=dev, dtype=torch.float32).contiguous()
-    with torch.cuda.device(dev):
+    with on_device(dev):
         check(_native.lib().mbnb_embedding_4bit(ptr(idx), idx.numel(), ptr(wp), ptr(wa), num, int(embedding_dim),
                                                 int(blocksize), _native.QUANT_CODE[quant_type], int(padding_idx is not None),
                                                 int(padding_idx) if padding_idx is not None else 0,
@@ -796,7 +836,7 @@ def embedding_8bit(input: Tensor, weight_int8: Tensor, weight_scales: Tensor, pa
     out = torch.empty(idx.numel(), dim, dtype=dtype, device=dev)
     w = weight_int8.contiguous()
     s = weight_scales.to(device=dev, dtype=torch.float32).contiguous()
-    with torch.cuda.device(dev):
+    with on_device(dev):
         check(_native.lib().mbnb_embedding_8bit(ptr(idx), idx.numel(), ptr(w), ptr(s), num, dim,
                                                 int(padding_idx is not None),
                                                 int(padding_idx) if padding_idx is not None else 0,
@@ -835,7 +875,7 @@ def outlier_linear(input: Tensor, weight_int8: Tensor, weight_scales: Tensor, ou
     out = torch.empty(M, N, dtype=dtype, device=dev)
     ws_bytes = int(_native.lib().mbnb_outlier_linear_workspace_bytes(M, K, n_out))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
+    with on_device(dev):
         check(_native.lib().mbnb_outlier_linear(ptr(x), dcode, M, K, ptr(w), ptr(s), N, ptr(oi), n_out, ptr(ow), ptr(b),
                                                    ptr(out), ptr(ws), ws_bytes, stream_ptr(dev)), "outlier_linear")
     return out.reshape(*input.shape[:-1], N)
@@ -868,7 +908,7 @@ def double_quant(
           else row_stats.to(device=A.device, dtype=torch.float32).contiguous().clone())
     oc = torch.empty(A.shape, dtype=torch.int8, device=A.device)
     orow = torch.empty(A.shape, dtype=torch.int8, device=A.device)
-    with torch.cuda.device(A.device):
+    with on_device(A.device):
         check(_native.lib().mbnb_double_quant(
             ptr(A), dcode, rows, cols, ptr(oc), ptr(orow), ptr(cs), ptr(rs), int(col_stats is not None),
             int(row_stats is not None), stream_ptr(A.device)), "double_quant")
@@ -896,7 +936,7 @@ def dequant_absmax(absmax_quant: Tensor, absmax_scales, blocksize: int = 256) ->
     if kind == 2 and q.dtype != torch.float32:
         q = q.float()       # the reference's `.float()` of the codes
     out = torch.empty(q.shape, dtype=torch.float32, device=q.device)
-    with torch.cuda.device(q.device):
+    with on_device(q.device):
         check(_native.lib().mbnb_dequant_absmax(ptr(q), kind, rows, num_blocks, ptr(scales), dq_blocks, int(blocksize),
                                                 ptr(out), stream_ptr(q.device)), "dequant_absmax")
     return out

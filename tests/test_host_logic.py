@@ -218,3 +218,17 @@ def test_synthetic_device_form_equals_the_numpy_form():
     for dt in (torch.float16, torch.bfloat16, torch.float32):
         for seed, std, shape in ((1234, 1.0, (257, 1031)), (4321, 0.02, (5, 70)), (7, 3.5, (100000,))):
             assert torch.equal(synthetic.normal(shape, dt, seed=seed, std=std), synthetic.normal_device(shape, dt, seed=seed, std=std, device="cpu"))
+
+
+def test_stream_and_device_helpers_accept_what_torch_accepts(monkeypatch):
+    """_native.stream_ptr / on_device take a torch.device, a device string or an index (round 4: the raw-stream fast path read `.index` off whatever it
+    was given -- on the string "cuda" that is str.index)."""
+    from mps_bitsandbytes_amd import _native
+    seen = []
+    monkeypatch.setattr(_native, "_raw_stream", lambda i: seen.append(i) or 1234)
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 0)
+    for d in ("cuda", "cuda:0", torch.device("cuda"), torch.device("cuda", 0), 0):
+        assert _native.stream_ptr(d).value == 1234
+        assert _native.on_device(d) is _native._NO_GUARD
+    assert seen == [0, 0, 0, 0, 0]
+    assert _native.on_device(torch.device("cuda", 1)) is not _native._NO_GUARD      # another device: a real guard
