@@ -21,11 +21,16 @@
 // the same operands (k-loop 81.7 us per 64 k-steps vs 83; the 32 MB store burst of the epilogue costs 8 us here) and
 // 116-124 us for the fused k_gemm256s.
 //
+// Round 4: the kernel is gemm_dense_body<..., FN> (a device function: one tile = 32 FN columns x 32 FM rows at (m0, n0)) under two wrappers --
+// k_gemm_dense (uniform 256-wide columns: every form, 16-bit / split-K / 256 x 128 tiles / int8 / int8 + outliers) and k_gemm_dense_nb (column-balanced
+// grids of 224 / 192 / 160-wide columns, FN = 7 / 6 / 5; plan and measurements: gemm_dense.hip) -- and the tile -> workgroup map is
+// gd_xcd_major + gd_patch_walk below (pseudo-patches dealt to the XCDs in turn, ragged 4 x 8 patches).
+//
 // Split-K (grid = tiles x slices): a slice covers `k_per_slice` of K and writes its f32 partial tile row-major into
 // partial[slice][M][N]; k_splitk_reduce_rm (gemm_mid.h) adds the slices in index order, then bias, rounding, cast.
 // Requirements (checked by the launcher): K % 64 == 0, k_per_slice % 64 == 0, 256 * max(K, ldw) * 2 < 2^31, 16-byte
 // aligned X / Wd rows (K % 8 == 0, ldw % 8 == 0, 16-byte aligned bases).  Output bits: the sums of a 16x16x32 MFMA chain equal those of the 32x32x16 chains of k_gemm256s
-// on every shape tested (tests/test_gpu_parity.py asserts equality with the fused kernel, and parity with the oracle).
+// on every shape tested (tests/test_gpu_parity.py asserts equality with the fused kernel -- k_gemm_fused4 since round 4 --, and parity with the oracle).
 #pragma once
 #include "gemm256.h"
 #include <type_traits>
