@@ -1447,3 +1447,35 @@ def test_matmul_4bit_takes_the_balanced_grid_where_its_plan_says_so():
     x2 = synthetic.normal((M, 256), dt, seed=824).to(DEV)
     assert lib.mbnb_gemm_dense(x2.data_ptr(), w2.data_ptr(), code, None, code, out2.data_ptr(), M, 11008, 256, 256, None, 0, 0, _native.stream_ptr(DEV)) == 0
     assert _native.last_kernel() == "dense 256x256"
+
+
+@pytest.mark.gpu
+def test_gemm_dense_balanced_grids_randomised():
+    """36 random forced grids (tile code 5 / 6 / 7, a random number of wider columns first; M 2304 .. 6000, N 2000 .. 9000 incl. odd values, K 128 .. 320)
+    against the uniform 256 x 256 tiles on NaN-prefilled outputs: every element written, every bit equal -- the tile walk (XCD-major pseudo-patches over
+    ragged patches) is a bijection at every grid size drawn, and the narrow bodies' edge handling (columns past N, rows past M) matches the wide one's."""
+    import random
+    lib = _native.lib()
+    rng = random.Random(20261005)
+    sp = _native.stream_ptr(DEV)
+    for case in range(36):
+        M = rng.randint(2304, 6000)
+        N = rng.choice([rng.randint(2000, 9000), 8 * rng.randint(250, 1100), 256 * rng.randint(9, 34)])
+        K = 64 * rng.randint(2, 5)
+        code = rng.choice([5, 6, 7])
+        cols_a = rng.randint(0, (N // 32) // (code + 1))
+        dt = rng.choice([torch.float16, torch.bfloat16])
+        x = synthetic.normal((M, K), dt, seed=9000 + case).to(DEV)
+        w = synthetic.normal((N, K), dt, seed=9100 + case, std=0.05).to(DEV)
+        bias = synthetic.normal((N,), dt, seed=9200 + case).to(DEV) if case % 3 == 0 else None
+        c = _native.DTYPE_CODE[dt]
+        outs = []
+        for sel in (2 << 8, (code << 8) | (cols_a << 16)):
+            out = torch.full((M, N), float("nan"), dtype=dt, device=DEV)
+            rc = lib.mbnb_gemm_dense(x.data_ptr(), w.data_ptr(), c, None if bias is None else bias.data_ptr(), c, out.data_ptr(), M, N, K, K, None, 0, 1 | sel, sp)
+            assert rc == 0, lib.mbnb_last_error()
+            outs.append(out)
+        name = _native.last_kernel()
+        assert name.startswith("dense_nb "), name
+        assert bool(torch.isfinite(outs[1].float()).all()), f"case {case}: M={M} N={N} K={K} {name}: an element was never written"
+        assert torch.equal(outs[0], outs[1]), f"case {case}: M={M} N={N} K={K} {dt} {name} differs from the uniform tiles"
