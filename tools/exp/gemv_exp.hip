@@ -21,9 +21,14 @@ extern "C" int exp_gemv(int dec, int nr, const void *X, const uint8_t *packed, c
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bf16_t *x = static_cast<const bf16_t *>(X);
     bf16_t *o = static_cast<bf16_t *>(out);
-    if (dec == 10) {    // k_gemv4_lean (K = 4096)
-        hipLaunchKernelGGL((k_gemv4_lean<bf16_t, bf16_t, MBNB_NF4, false, 2>), dim3((unsigned)((N + 3) / 4)), dim3(256), (size_t)K * 2, st, x, packed, am,
-                           (const bf16_t *)nullptr, o, N, K);
+    if (dec == 10 || dec >= 100) {    // k_gemv4_lean (K = 4096); dec >= 100: with dec KiB of dynamic LDS per workgroup (fewer resident workgroups per CU)
+        const size_t lds = dec >= 100 ? (size_t)(dec - 100) * 1024 : (size_t)K * 2;
+        auto kern = k_gemv4_lean<bf16_t, bf16_t, MBNB_NF4, false, 2>;
+        if (lds > 65536) {
+            static size_t raised = 0;
+            if (lds > raised) { if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -3; raised = lds; }
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)((N + 3) / 4)), dim3(256), lds, st, x, packed, am, (const bf16_t *)nullptr, o, N, K);
         return (int)hipGetLastError();
     }
     if (nr == 1) { if (dec == 0) return run<0, 1>(x, packed, am, o, N, K, st); if (dec == 1) return run<1, 1>(x, packed, am, o, N, K, st); return run<2, 1>(x, packed, am, o, N, K, st); }
