@@ -904,6 +904,10 @@ def main():
         print(json.dumps({"error": f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU"}))
         sys.exit(2)
     distributed = world > 1
+    if distributed:
+        # RCCL shares device buffers between the ranks through dmabuf IPC on this driver; the legacy mode fails with hipIpcGetMemHandle: invalid argument.
+        # (Set before the first HIP call of the process; a launcher's own setting wins.)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         print(json.dumps({"error": "no GPU visible; bench.py measures the HIP path only", "rank": rank, "world": world}), flush=True)
         sys.exit(2)
