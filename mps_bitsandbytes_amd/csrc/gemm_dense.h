@@ -48,6 +48,10 @@ template <int N, class F> __device__ __forceinline__ void gd_static_for(F &&f) {
 #ifndef GD_ABL
 #define GD_ABL 0        // diagnostic builds (timing only): 1 no LDS-DMA pieces in the k-loop, 2 no fragment reads in the k-loop, 4 no barriers in the k-loop
 #endif
+#ifndef GD_B_TILE_MAJOR
+#define GD_B_TILE_MAJOR 0   // diagnostic builds (tools/exp/dense_tm_exp.hip): Wd is a TILE-MAJOR scratch [n tile of 256 rows][k tile of 64][row][128 B] --
+                            // every LDS-DMA piece of the weight operand is 1 KiB contiguous instead of 8 lines `ldw` apart (uniform 256-wide tiles only)
+#endif
 #ifndef GD_STAMPS
 #define GD_STAMPS 0     // diagnostic builds: 1 the vmcnt wait of barrier 2, 2 barrier 2 itself, 3 the lgkmcnt wait of barrier 1, 4 barrier 1 itself
 #endif
@@ -146,16 +150,29 @@ __device__ __forceinline__ void gemm_dense_body(const T *__restrict__ X, const T
     typedef int i32x4_t __attribute__((ext_vector_type(4)));
     i32x4_t rs_a, rs_b;
     {
+#if GD_B_TILE_MAJOR
+        // tile-major scratch: the tile column's blocks [K / 64][256 rows][64 k] follow each other; rows past N are zero in the scratch
+        const uint64_t pa = reinterpret_cast<uint64_t>(X + m0 * K + k_begin), pb = reinterpret_cast<uint64_t>(Wd + (n0 >> 8) * (K >> 6) * 16384 + (k_begin >> 6) * 16384);
+        const int64_t rows_a = M - m0 < TM ? M - m0 : TM, rows_b = 256;
+        rs_a = i32x4_t{(int)(uint32_t)pa, (int)(uint32_t)(pa >> 32), (int)(rows_a * K * 2), 0x00020000};
+        rs_b = i32x4_t{(int)(uint32_t)pb, (int)(uint32_t)(pb >> 32), (int)((k_len >> 6) * 32768), 0x00020000};
+        (void)rows_b;
+#else
         const uint64_t pa = reinterpret_cast<uint64_t>(X + m0 * K + k_begin), pb = reinterpret_cast<uint64_t>(Wd + n0 * ldw + k_begin);
         const int64_t rows_a = M - m0 < TM ? M - m0 : TM, rows_b = N - n0 < TN ? N - n0 : TN;
         rs_a = i32x4_t{(int)(uint32_t)pa, (int)(uint32_t)(pa >> 32), (int)(rows_a * K * 2), 0x00020000};
         rs_b = i32x4_t{(int)(uint32_t)pb, (int)(uint32_t)(pb >> 32), (int)(rows_b * ldw * 2), 0x00020000};
+#endif
     }
     int voff_a[FM], voff_b[FN];
 #pragma unroll
     for (int pl = 0; pl < FN; pl++) {
         const int row = 8 * (FN * wave + pl) + (lane >> 3);
+#if GD_B_TILE_MAJOR
+        voff_b[pl] = row * 128 + 16 * ((lane & 7) ^ ((row >> 1) & 7));
+#else
         voff_b[pl] = (int)(row * ldw * 2) + 16 * ((lane & 7) ^ ((row >> 1) & 7));
+#endif
     }
 #pragma unroll
     for (int pl = 0; pl < FM; pl++) {
@@ -192,6 +209,9 @@ __device__ __forceinline__ void gemm_dense_body(const T *__restrict__ X, const T
         const uint32_t dst = (q < FM ? c.lwa : c.lwb) + (uint32_t)(stage * P_IMG + pl * 1024);
         const int vo = (q < FM) ? voff_a[pl] : voff_b[pl];
         const i32x4_t rs = (q < FM) ? c.ra : c.rb;
+#if GD_B_TILE_MAJOR
+        if constexpr (q >= FM) kb = __builtin_amdgcn_readfirstlane(kb << 8);     // k tile t: byte 128 t of a row-major row, block 32768 t of the tile-major scratch
+#endif
 #if GD_M0_GROUP
         if constexpr ((pl & 3) != 0) {
             asm volatile("buffer_load_dwordx4 %0, %1, %2 offen offset:%3 lds" ::"v"(vo), "s"(rs), "s"(kb), "n"((pl & 3) * 1024) : "memory", "m0");
